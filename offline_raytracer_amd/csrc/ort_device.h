@@ -1,0 +1,337 @@
+/*
+ * ort_device.h -- gfx950 device functions of the path-trace hot path.
+ *
+ * What each function must reproduce is the reference's scalar f32 arithmetic, operation
+ * for operation (paths relative to /root/reference/code); built with -ffp-contract=off,
+ * IEEE divide/sqrt (hipcc default), denormals on.  "sic" marks reference oddities that are
+ * part of its results.
+ */
+#ifndef ORT_DEVICE_H
+#define ORT_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ort_detmath.h"
+
+namespace ortd {
+
+#ifdef ORT_HOST_SIM /* developer harness only (tools/host_sim.cpp); never defined in a product build */
+#define ORT_D static inline
+#else
+#define ORT_D __device__ __forceinline__
+#endif
+
+struct V3 { float x, y, z; };
+
+constexpr float kPi = 3.14159265358979323846264338327950288419716939937510582097494459230f; /* platform.h:44 */
+constexpr float kEuler = 2.71828182845904523536028747135266249f;                            /* ray.cpp:4 */
+constexpr float kHitTMin = 0.000001f;                                                       /* ray.cpp:5 */
+constexpr float kRoughness = 0.01f;                                                         /* ray.cpp:1194 */
+constexpr float kEps = 0.0001f;                                                             /* ray.cpp:1196 */
+
+ORT_D V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+ORT_D V3 add(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+ORT_D V3 sub(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+ORT_D V3 neg(V3 a) { return mk(-a.x, -a.y, -a.z); }
+ORT_D V3 scale(float s, V3 a) { return mk(s * a.x, s * a.y, s * a.z); }
+ORT_D V3 divs(V3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }            /* three divides, math.h:234-244 */
+ORT_D V3 had(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+ORT_D float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }        /* math.h:319-323 */
+ORT_D float len2(V3 a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+ORT_D float len(V3 a) { return __builtin_sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
+ORT_D V3 cross(V3 a, V3 b) {                                                      /* math.h:280-290 */
+    return mk(a.y * b.z - b.y * a.z, b.x * a.z - a.x * b.z, a.x * b.y - b.x * a.y);
+}
+ORT_D float absr(float v) { if (v <= 0.0f) v *= -1.0f; return v; }                /* intrinsic.h:132-143 (+0 -> -0) */
+ORT_D float sq(float v) { return v * v; }
+ORT_D bool ceq(float a, float b) { float d = a - b; return d >= -0.000001f && d < 0.000001f; } /* math.h:9-22 */
+ORT_D float sgn(float a) { return (a >= 0.0f) ? 1.0f : -1.0f; }                   /* types.h:52 */
+ORT_D float rmin(float a, float b) { return (a < b) ? a : b; }                    /* types.h:51: NaN -> b */
+ORT_D float rmax(float a, float b) { return (a > b) ? a : b; }                    /* types.h:50: NaN -> b */
+ORT_D V3 normalize(V3 a) {                                                        /* math.h:298-310 */
+    float l = len(a);
+    if (!ceq(l, 0.0f)) return divs(a, l);
+    return mk(0, 0, 0);
+}
+ORT_D bool isnan3(V3 v) { return (v.x != v.x) || (v.y != v.y) || (v.z != v.z); }
+ORT_D bool isinf1(float v) { return (om_f32_bits(v) & 0x7fffffffu) == 0x7f800000u; }
+ORT_D bool isinf3(V3 v) { return isinf1(v.x) || isinf1(v.y) || isinf1(v.z); }
+
+/* ---- RNG: random.h:5-117 --------------------------------------------------------------- */
+ORT_D void rng_step(uint32_t &s) { s ^= s << 13; s ^= s >> 17; s ^= s >> 5; }     /* sic: third shift is right */
+ORT_D float rng_01(uint32_t &s) { rng_step(s); return (float)s / 4294967296.0f; } /* (f32)U32_Max == 2^32 */
+ORT_D float rng_between(uint32_t &s, float lo, float hi) { rng_step(s); return lo + (hi - lo) * rng_01(s); } /* sic: two steps */
+
+ORT_D uint32_t fmix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    return h;
+}
+ORT_D uint32_t job_seed(uint32_t master, uint32_t job) {
+    uint32_t h = fmix32(master ^ (job * 2654435761u));
+    return h ? h : 1u;
+}
+
+/* ---- material record (DevMaterial, 4 x float4) ------------------------------------------- */
+struct Mat {
+    V3 kd; float ior;
+    V3 ks; uint32_t is_light;
+    V3 kt;
+    V3 emit;
+};
+ORT_D Mat load_mat(const float4 *mats, uint32_t index) {
+    const float4 *p = mats + 4u * index;
+    float4 a = p[0], b = p[1], c = p[2], d = p[3];
+    Mat m;
+    m.kd = mk(a.x, a.y, a.z); m.ior = a.w;
+    m.ks = mk(b.x, b.y, b.z); m.is_light = om_f32_bits(b.w);
+    m.kt = mk(c.x, c.y, c.z);
+    m.emit = mk(d.x, d.y, d.z);
+    return m;
+}
+
+/* ---- BSDF: ray.cpp:825-1161 ------------------------------------------------------------- */
+ORT_D V3 fresnel(V3 ks, float l_dot_h) {                                          /* ray.cpp:825-831, sic */
+    float k = 1 - ort_powf(1.0f - absr(l_dot_h), 5.0f);
+    return add(ks, scale(k, sub(mk(1, 1, 1), ks)));
+}
+ORT_D float ggx_d(V3 N, V3 H, float rough) {                                      /* ray.cpp:834-865 */
+    float result = 0.0f, ndh = dot(N, H);
+    if (ndh > 0.0f) {
+        float r2 = sq(rough);
+        float tan_t = __builtin_sqrtf(1.0f - sq(ndh)) / ndh;
+        float denom = kPi * ort_powf(ndh, 4.0f) * sq(r2 + sq(tan_t));
+        if (!ceq(denom, 0.0f)) result = r2 / denom;
+    }
+    return result;
+}
+ORT_D float geom(V3 w, V3 N, V3 m, float rough) {                                 /* ray.cpp:868-897 */
+    float result = 0.0f, wdn = dot(w, N), wdm = dot(w, m);
+    if (!ceq(wdm, 0.0f) && (wdn / wdm) > 0) {
+        if (wdm > 1.0f) {
+            result = 1.0f;
+        } else {
+            float tan_t = __builtin_sqrtf(1.0f - sq(wdn)) / wdn;
+            if (!ceq(tan_t, 0.0f)) {
+                float r2 = sq(rough);
+                result = 2.0f / (1.0f + __builtin_sqrtf(1 + r2 * sq(tan_t)));
+            }
+        }
+    }
+    return result;
+}
+ORT_D float radicand(V3 m, V3 wo, float n) { return 1 - sq(n) * (1 - sq(dot(wo, m))); } /* ray.cpp:899-904 */
+struct Beer { float ni, no, n; };
+ORT_D Beer beer(V3 N, V3 wo, float ior) {                                         /* ray.cpp:914-933 */
+    Beer r;
+    if (dot(N, wo) >= 0.0f) { r.ni = 1.0f; r.no = ior; } else { r.ni = ior; r.no = 1.0f; }
+    r.n = r.ni / r.no;
+    return r;
+}
+
+ORT_D V3 eval_scattering(V3 N, V3 wi, V3 wo, const Mat &mt, float rough, float dist) { /* ray.cpp:936-1005 */
+    V3 Ed = divs(mt.kd, kPi);
+    V3 H = scale(sgn(dot(wi, N)), normalize(add(wo, wi)));
+    float wi_h = dot(wi, H);
+    V3 Es = mk(0, 0, 0), Et = mk(0, 0, 0);
+    float wi_n = dot(wi, N), wo_n = dot(wo, N);
+    if (wi_h > 0.0f && len2(mt.ks) > 0.0f) {
+        V3 F = fresnel(mt.ks, wi_h);
+        float D = ggx_d(N, H, rough);
+        float G = geom(wi, N, H, rough) * geom(wo, N, H, rough);
+        Es = scale((D * G) / (4.0f * absr(wi_n) * absr(wo_n)), F);
+    }
+    if (len2(mt.kt) > 0.0f) {
+        V3 At = mk(1, 1, 1);
+        if (wo_n < 0) {                                                           /* sic: logf(0) = -inf is relied on */
+            At.x = ort_powf(kEuler, dist * ort_logf(mt.kt.x));
+            At.y = ort_powf(kEuler, dist * ort_logf(mt.kt.y));
+            At.z = ort_powf(kEuler, dist * ort_logf(mt.kt.z));
+        }
+        Beer bn = beer(N, wo, mt.ior);
+        V3 m = normalize(neg(add(scale(bn.ni, wi), scale(bn.no, wo))));
+        float r = radicand(m, wo, bn.n);
+        if (r < 0.0f) {
+            if (len2(mt.ks) > 0.0f) Et = had(At, Es);
+        } else {
+            float wi_m = dot(wi, m), wo_m = dot(wo, m);
+            V3 F = sub(mk(1, 1, 1), fresnel(mt.ks, wi_m));
+            float D = ggx_d(N, m, rough);
+            float G = geom(wi, N, m, rough) * geom(wo, N, m, rough);
+            float denom = (absr(wi_n) * absr(wo_n) * sq(bn.ni * wi_m + bn.no * wo_m));
+            if (!ceq(denom, 0.0f)) {
+                V3 nom = scale(D * G * absr(wi_m) * absr(wo_m) * sq(bn.no), F);
+                Et = had(At, divs(nom, denom));
+            }
+        }
+    }
+    return scale(absr(wi_n), add(add(Ed, Es), Et));
+}
+
+ORT_D float pdf_brdf(V3 N, V3 wi, V3 wo, float rough, const Mat &mt) {            /* ray.cpp:1007-1063 */
+    float kd = len(mt.kd), ks = len(mt.ks), kt = len(mt.kt);
+    float s = kd + ks + kt;
+    float pd_c = kd / s, ps_c = ks / s, pt_c = kt / s;
+    float pd = absr(dot(wi, N)) / kPi;
+    V3 H = scale(sgn(dot(N, wi)), normalize(add(wo, wi)));
+    float n_h = dot(N, H), wi_h = dot(wi, H);
+    float ps = 0.0f;
+    if (ps_c > 0.0f) {
+        float denom = (4.0f * absr(wi_h));
+        if (!ceq(denom, 0.0f)) {
+            float D = ggx_d(N, H, rough);
+            ps = D * absr(n_h) / denom;
+        }
+    }
+    Beer bn = beer(N, wo, mt.ior);
+    V3 m = normalize(neg(add(scale(bn.ni, wi), scale(bn.no, wo))));
+    float r = radicand(m, wo, bn.n);
+    float pt = ps;                                                                /* sic */
+    if (pt_c > 0.0f && r >= 0.0f) {
+        float n_m = dot(N, m), wi_m = dot(wi, m), wo_m = dot(wo, m);
+        float denom = sq(bn.no * wo_m + bn.no * wo_m);                            /* sic, ray.cpp:1054 */
+        if (!ceq(denom, 0.0f)) {
+            float D = ggx_d(N, m, rough);
+            pt = D * absr(n_m) * sq(bn.no) * absr(wi_m) / denom;
+        }
+    }
+    return pd_c * pd + ps_c * ps + pt_c * pt;
+}
+
+ORT_D V3 sample_lobe(V3 N, float c, float phi) {                                  /* ray.cpp:1065-1091 */
+    N = normalize(N);
+    float s = __builtin_sqrtf(1.0f - c * c);
+    V3 K = mk(s * ort_cosf(phi), s * ort_sinf(phi), c);
+    if (absr(N.z - 1.0f) < 0.0001f) return K;
+    if (absr(N.z + 1.0f) < 0.0001f) return mk(K.x, -K.y, -K.z);
+    V3 B = normalize(mk(-N.y, N.x, 0));
+    V3 C = cross(N, B);
+    return add(add(scale(K.x, B), scale(K.y, C)), scale(K.z, N));
+}
+
+ORT_D V3 sample_brdf(uint32_t &rng, V3 N, V3 wo, float rough, const Mat &mt, bool &is_trans) { /* ray.cpp:1100-1161 */
+    float kd = len(mt.kd), ks = len(mt.ks), kt = len(mt.kt);
+    float s = kd + ks + kt;
+    float pd_c = kd / s, ps_c = ks / s;
+    float e0 = rng_01(rng), e1 = rng_01(rng), choice = rng_01(rng);
+    V3 wi;
+    is_trans = false;
+    if (choice < pd_c) {
+        wi = sample_lobe(N, __builtin_sqrtf(e0), 2.0f * kPi * e1);
+    } else {
+        float ct = ort_cosf(ort_atan2f(rough * __builtin_sqrtf(e0), __builtin_sqrtf(1.0f - e0)));
+        V3 m = sample_lobe(N, ct, 2.0f * kPi * e1);
+        bool reflect = (choice >= pd_c && choice < pd_c + ps_c);
+        Beer bn = beer(N, wo, mt.ior);
+        float r = radicand(m, wo, bn.n);
+        if (reflect || r < 0.0f) {
+            wi = sub(scale(2.0f * absr(dot(wo, m)), m), wo);
+        } else {
+            wi = sub(scale(bn.n * dot(wo, m) - sgn(dot(wo, N)) * __builtin_sqrtf(r), m), scale(bn.n, wo));
+            is_trans = true;
+        }
+    }
+    return normalize(wi);
+}
+
+/* ---- intersectors ----------------------------------------------------------------------- */
+/* ray.cpp:63-115 with e1, e2, n = cross(e1,e2) precomputed (same f32 expressions).  Returns
+   the reference's hit_t (-1 = no hit).  Evaluation order differs (u, then v, then t) but
+   every value is the reference's own expression. */
+ORT_D float hit_triangle(V3 v0, V3 e1, V3 e2, V3 o, V3 d) {
+    V3 pv = cross(d, e2);
+    float det = dot(pv, e1);
+    if (!(det <= -0.000001f || det >= 0.000001f)) return -1.0f;
+    V3 T = sub(o, v0);
+    float u = dot(pv, T) / det;
+    if (!(u >= 0.0f)) return -1.0f;
+    V3 a = cross(T, e1);
+    float v = dot(a, d) / det;
+    if (!(v >= 0.0f && u + v <= 1.0f)) return -1.0f;
+    float t = dot(a, e2) / det;
+    if (!(t >= kHitTMin)) return -1.0f;
+    return t;
+}
+
+ORT_D float hit_sphere(V3 c, float rad, V3 o, V3 d, V3 &n) {                      /* ray.cpp:132-190 */
+    float ht = -1.0f;
+    V3 rel = sub(o, c);
+    float a = dot(d, d), b = dot(d, rel), cc = dot(rel, rel) - rad * rad;
+    float root = b * b - a * cc;
+    const float tol = 0.00001f;
+    if (root >= tol) {
+        float sr = __builtin_sqrtf(root);
+        float tn = (-b - sr) / a, tp = (-b + sr) / a;
+        float t = (tn < 0.0f) ? tp : tn;
+        if (t > kHitTMin) {
+            ht = t;
+            n = scale(1.0f, sub(add(o, scale(ht, d)), c));
+        }
+    } else if (root < tol && root > -tol) {
+        float t = (-b) / (2 * a);
+        if (t > kHitTMin) {
+            ht = t;
+            n = sub(add(o, scale(ht, d)), c);
+        }
+    }
+    return ht;
+}
+
+ORT_D float hit_aab(V3 lo, V3 hi, V3 o, V3 d, V3 &n) {                            /* ray.cpp:206-283 */
+    float ht = -1.0f;
+    V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    V3 t0 = had(sub(lo, o), inv), t1 = had(sub(hi, o), inv);
+    V3 tmin = mk(rmin(t0.x, t1.x), rmin(t0.y, t1.y), rmin(t0.z, t1.z));
+    V3 tmax = mk(rmax(t0.x, t1.x), rmax(t0.y, t1.y), rmax(t0.z, t1.z));
+    float max_of_min = rmax(rmax(tmin.x, tmin.y), tmin.z);
+    float min_of_max = rmin(rmin(tmax.x, tmax.y), tmax.z);
+    if (min_of_max >= max_of_min) {
+        float tx = t0.x, ty = t0.y, tz = t0.z;
+        float sx = -1.0f, sy = -1.0f, sz = -1.0f;
+        if (tx > t1.x) { tx = t1.x; sx = 1.0f; }
+        if (ty > t1.y) { ty = t1.y; sy = 1.0f; }
+        if (tz > t1.z) { tz = t1.z; sz = 1.0f; }
+        float best = tx;
+        V3 bn = mk(sx, 0, 0);
+        if (best < ty) { best = ty; bn = mk(0, sy, 0); }
+        if (best < tz) { best = tz; bn = mk(0, 0, sz); }
+        ht = max_of_min; /* sic: may be negative; callers threshold */
+        n = bn;
+    }
+    return ht;
+}
+
+/* ray.cpp:286-352 with rotation_matrix_along_z(axis) (ray.cpp:8-33) and |axis| precomputed */
+ORT_D float hit_cylinder(V3 base, float radius, V3 r0, V3 r1, V3 r2, float axis_len, V3 o, V3 d, V3 &n) {
+    float ht = -1.0f;
+    V3 rel = sub(o, base);
+    o = mk(dot(r0, rel), dot(r1, rel), dot(r2, rel));
+    d = mk(dot(r0, d), dot(r1, d), dot(r2, d));
+    float t_bot = (-o.z) / d.z;
+    float t_top = (axis_len - o.z) / d.z;
+    float smin = rmin(t_bot, t_top), smax = rmax(t_bot, t_top);
+    float a = d.x * d.x + d.y * d.y;
+    float b = d.x * o.x + d.y * o.y;
+    float c = (o.x * o.x + o.y * o.y) - radius * radius;
+    float det = b * b - a * c;
+    if (det >= 0.0f) {
+        float sr = __builtin_sqrtf(det);
+        float cmin = (-b - sr) / a, cmax = (-b + sr) / a;
+        float tin = rmax(smin, cmin), tout = rmin(smax, cmax);
+        if (tin <= tout) {
+            ht = tin; /* sic: may be negative */
+            V3 ln = mk(0, 1, 0); /* sic: cap "normal" */
+            if (smin < cmin) {
+                V3 p = add(o, scale(ht, d));
+                ln = mk(p.x, p.y, 0);
+            }
+            /* transpose(rotation) * ln */
+            n = mk(dot(mk(r0.x, r1.x, r2.x), ln), dot(mk(r0.y, r1.y, r2.y), ln), dot(mk(r0.z, r1.z, r2.z), ln));
+        }
+    }
+    return ht;
+}
+
+} // namespace ortd
+
+#endif

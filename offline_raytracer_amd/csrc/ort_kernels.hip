@@ -1,0 +1,747 @@
+/*
+ * ort_kernels.hip -- the persistent path-trace kernel for gfx950 and its launcher.
+ *
+ * One GPU lane executes one JOB at a time; a job is one call of the reference function
+ * tiled_raytrace_bvh (code/ray.cpp:1178-1466): a pixel rect rendered serially with one
+ * xorshift stream.  The lane is a small state machine (new job -> pixel -> sample ->
+ * bounce) that alternates "produce the next ray" with an interruptible closest-hit
+ * traversal; a lane whose path ends immediately starts its next sample / pixel / job, so
+ * waves stay full without moving path state between lanes.
+ *
+ * Traversal replaces raycast_bvh (ray.cpp:624-822): ordered depth-first walk of the
+ * 2-wide tree of ort_tree.cpp with a per-lane stack whose first entries live in LDS
+ * (column-per-lane, conflict-free) and whose tail spills to scratch.
+ */
+#include <hip/hip_runtime.h>
+
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "ort_device.h"
+#include "ort_scene.h"
+
+namespace ort {
+
+using namespace ortd;
+
+constexpr int kBlock = 256;      /* 4 waves */
+constexpr int kLdsStack = 24;    /* entries per lane in LDS: 24 * 256 * 4 B = 24 KB per block */
+constexpr int kSpillStack = 64;  /* scratch tail; ort_tree.cpp bounds the depth at 60; the octree fallback needs 7*10+8 */
+
+struct SceneView {
+    const float4 *nodes;      /* 4 per node */
+    const float4 *tris;       /* 3 per triangle: v0 e1 e2 n (12 floats) */
+    const uint32_t *tri_mat;
+    const float4 *spheres;    /* 1 per sphere: c.xyz r */
+    const uint32_t *sphere_mat;
+    const float4 *boxes;      /* 2 per box */
+    const uint32_t *box_mat;
+    const float4 *cyls;       /* 4 per cylinder */
+    const uint32_t *cyl_mat;
+    const float4 *materials;  /* 4 per material */
+    const uint32_t *light_is_sphere;
+    uint32_t light_count;
+    float cam[12];            /* p, x_axis, y_axis, z_axis */
+    /* reference-compatible octree (ort_reftree.cpp): visibility chains + exact fallback */
+    const float4 *ref_nodes;   /* 3 per node */
+    const uint32_t *ref_recs;
+    const float4 *chain_boxes; /* 2 per chain entry */
+    const uint32_t *tri_chain, *sphere_chain, *box_chain, *cyl_chain;
+};
+
+enum : int { JOBS_EXPLICIT = 0, JOBS_PIXEL = 1, JOBS_CHUNK = 2 };
+
+struct RenderView {
+    int mode;
+    const ort_tile_job *jobs;
+    uint32_t *final_states;
+    unsigned long long job_count; /* size of the job index space */
+    int W, H, x0, y0, x1, y1;
+    uint32_t seed, spp, chunk, nchunks;
+    float rr;
+    uint32_t shard_index, shard_count, blocks_w, my_blocks;
+    float *out;      /* W*H*3 */
+    float *partial;  /* nchunks * W*H*3 (CHUNK) */
+    unsigned long long *next_job;
+    unsigned long long *counters; /* paths rays node_tests tri_tests analytic_tests fallback_rays */
+};
+
+struct DeviceScene {
+    int device = -1;
+    void *nodes = nullptr, *tris = nullptr, *tri_mat = nullptr, *spheres = nullptr, *sphere_mat = nullptr;
+    void *boxes = nullptr, *box_mat = nullptr, *cyls = nullptr, *cyl_mat = nullptr, *materials = nullptr;
+    void *light_is_sphere = nullptr;
+    uint32_t light_count = 0;
+    void *ref_nodes = nullptr, *ref_recs = nullptr, *chain_boxes = nullptr;
+    void *tri_chain = nullptr, *sphere_chain = nullptr, *box_chain = nullptr, *cyl_chain = nullptr;
+    unsigned long long *ctrl = nullptr; /* [0] next_job, [1..5] counters */
+    float *partial = nullptr;
+    size_t partial_bytes = 0;
+    float *staging = nullptr;
+    size_t staging_bytes = 0;
+    void *jobs = nullptr;
+    size_t jobs_bytes = 0;
+    void *states = nullptr;
+    size_t states_bytes = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int cu_count = 0;
+};
+
+/* ---- kernel ---------------------------------------------------------------------------- */
+enum : int { PS_NEED_JOB = 0, PS_PIXEL = 1, PS_SAMPLE = 2, PS_HIT = 3, PS_DONE = 4 };
+
+#ifdef ORT_HOST_SIM /* one simulated lane: tools/host_sim.cpp */
+#define ORT_BALLOT(p) ((p) ? 1ull : 0ull)
+#define ORT_POPC64(m) __builtin_popcountll(m)
+#define ORT_NEXT_JOB(p) ((*(p))++)
+#define ORT_COUNT(p, v) (*(p) += (v))
+#ifndef ORT_SIM_PIXEL_HOOK
+#define ORT_SIM_PIXEL_HOOK(x, y, rng)
+#endif
+#ifndef ORT_SIM_RAY_HOOK
+#define ORT_SIM_RAY_HOOK(x, y, o, d, t, n, m)
+#endif
+#else
+#define ORT_SIM_PIXEL_HOOK(x, y, rng)
+#define ORT_SIM_RAY_HOOK(x, y, o, d, t, n, m)
+#define ORT_BALLOT(p) __ballot(p)
+#define ORT_POPC64(m) __popcll(m)
+#define ORT_NEXT_JOB(p) atomicAdd((p), 1ull)
+#define ORT_COUNT(p, v) atomicAdd((p), (v))
+#endif
+
+
+constexpr uint32_t kNoPrim = 0xffffffffu;
+
+/* one primitive against the ray, exactly as raycast_bvh does per record (ray.cpp:647-716):
+   accept when hit_t >= 1e-6 and strictly closer than the best so far */
+template <bool COUNTERS>
+ORT_D void test_prim(const SceneView &sv, uint32_t kind, uint32_t slot, V3 org, V3 dir, float &best_t, V3 &hit_n,
+                     uint32_t &hit_prim, unsigned long long &c_tris, unsigned long long &c_analytic) {
+    float t;
+    V3 n = mk(0, 0, 0);
+    if (kind == PRIM_TRI) {
+        const float4 *tp = sv.tris + 3u * slot;
+        float4 a = tp[0], b = tp[1], c = tp[2];
+        if (COUNTERS) c_tris++;
+        t = hit_triangle(mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), mk(b.z, b.w, c.x), org, dir);
+        n = mk(c.y, c.z, c.w);
+    } else if (kind == PRIM_SPHERE) {
+        float4 s = sv.spheres[slot];
+        if (COUNTERS) c_analytic++;
+        t = hit_sphere(mk(s.x, s.y, s.z), s.w, org, dir, n);
+    } else if (kind == PRIM_BOX) {
+        float4 lo = sv.boxes[2u * slot], hi = sv.boxes[2u * slot + 1u];
+        if (COUNTERS) c_analytic++;
+        t = hit_aab(mk(lo.x, lo.y, lo.z), mk(hi.x, hi.y, hi.z), org, dir, n);
+    } else {
+        const float4 *cp = sv.cyls + 4u * slot;
+        float4 a = cp[0], b = cp[1], c = cp[2], d = cp[3];
+        if (COUNTERS) c_analytic++;
+        t = hit_cylinder(mk(a.x, a.y, a.z), a.w, mk(b.x, b.y, b.z), mk(b.w, c.x, c.y), mk(c.z, c.w, d.x), d.y, org, dir, n);
+    }
+    if (t >= kHitTMin && t < best_t) {
+        best_t = t;
+        hit_n = n;
+        hit_prim = (kind << 28) | slot;
+    }
+}
+
+/* the reference's child test without its "closer than best" clause (ray.cpp:788-803):
+   origin inside the box (half-open), or the slab test enters at t >= 1e-6 */
+ORT_D bool ref_node_admits(V3 lo, V3 hi, V3 org, V3 dir) {
+    if ((org.x >= lo.x && org.x < hi.x) && (org.y >= lo.y && org.y < hi.y) && (org.z >= lo.z && org.z < hi.z)) return true;
+    V3 n;
+    return hit_aab(lo, hi, org, dir, n) >= kHitTMin;
+}
+
+/* would the reference have reached this primitive?  Every node box on the way down must admit the ray. */
+ORT_D bool chain_admits(const SceneView &sv, uint32_t prim, V3 org, V3 dir) {
+    uint32_t kind = prim >> 28, slot = prim & 0x00ffffffu;
+    uint32_t word = (kind == PRIM_TRI) ? sv.tri_chain[slot]
+                  : (kind == PRIM_SPHERE) ? sv.sphere_chain[slot]
+                  : (kind == PRIM_BOX) ? sv.box_chain[slot] : sv.cyl_chain[slot];
+    uint32_t len = word >> 28, first = word & 0x0fffffffu;
+    for (uint32_t i = 0; i < len; ++i) {
+        float4 lo = sv.chain_boxes[2u * (first + i)], hi = sv.chain_boxes[2u * (first + i) + 1u];
+        if (!ref_node_admits(mk(lo.x, lo.y, lo.z), mk(hi.x, hi.y, hi.z), org, dir)) return false;
+    }
+    return true;
+}
+
+/* exact fallback: raycast_bvh (ray.cpp:624-822) on the reference-compatible octree, depth-first.
+   Same admission rule and same per-record acceptance as the reference; only the visiting order
+   differs (it matters only for bit-equal-t ties). */
+template <bool COUNTERS>
+ORT_D void ref_raycast(const SceneView &sv, V3 org, V3 dir, uint32_t *lds_stack, uint32_t *spill, int tid, float &best_t,
+                       V3 &hit_n, uint32_t &hit_prim, unsigned long long &c_nodes, unsigned long long &c_tris,
+                       unsigned long long &c_analytic) {
+    best_t = 3.402823466e+38f;
+    hit_n = mk(0, 0, 0);
+    hit_prim = kNoPrim;
+    int sp = 0;
+    uint32_t node = 0;
+    for (;;) {
+        const float4 *np = sv.ref_nodes + 3u * node;
+        float4 a = np[0], b = np[1], c = np[2];
+        int32_t first_child = (int32_t)om_f32_bits(a.w);
+        uint32_t rec_first = om_f32_bits(b.w), rec_count = om_f32_bits(c.x);
+        for (uint32_t r = 0; r < rec_count; ++r) {
+            uint32_t rec = sv.ref_recs[rec_first + r];
+            test_prim<COUNTERS>(sv, rec >> 28, rec & 0x00ffffffu, org, dir, best_t, hit_n, hit_prim, c_tris, c_analytic);
+        }
+        if (first_child >= 0) {
+            for (uint32_t k = 0; k < 8u; ++k) {
+                uint32_t ci = (uint32_t)first_child + k;
+                const float4 *cp = sv.ref_nodes + 3u * ci;
+                float4 ca = cp[0], cb = cp[1], cc = cp[2];
+                uint32_t flags = om_f32_bits(cc.y);
+                bool leaf_with_records = (flags & 3u) == 3u;
+                bool has_children = (int32_t)om_f32_bits(ca.w) >= 0;
+                if (!(leaf_with_records || has_children)) continue;
+                V3 lo = mk(ca.x, ca.y, ca.z), hi = mk(cb.x, cb.y, cb.z);
+                bool add = (org.x >= lo.x && org.x < hi.x) && (org.y >= lo.y && org.y < hi.y) && (org.z >= lo.z && org.z < hi.z);
+                if (!add) {
+                    V3 n;
+                    float t = hit_aab(lo, hi, org, dir, n);
+                    if (COUNTERS) c_nodes++;
+                    add = (t >= kHitTMin && t < best_t);
+                }
+                if (add) {
+                    if (sp < kLdsStack) lds_stack[sp * kBlock + tid] = ci;
+                    else if (sp - kLdsStack < kSpillStack) spill[sp - kLdsStack] = ci;
+                    sp++;
+                }
+            }
+        }
+        if (sp == 0) break;
+        sp--;
+        node = (sp < kLdsStack) ? lds_stack[sp * kBlock + tid] : spill[sp - kLdsStack];
+    }
+}
+
+template <bool COUNTERS>
+ORT_D void pt_lane(const SceneView &sv, const RenderView &rv, uint32_t *lds_stack, const int tid) {
+    uint32_t spill[kSpillStack];
+
+    const V3 cam_p = mk(sv.cam[0], sv.cam[1], sv.cam[2]);
+    const V3 cam_x = mk(sv.cam[3], sv.cam[4], sv.cam[5]);
+    const V3 cam_y = mk(sv.cam[6], sv.cam[7], sv.cam[8]);
+    const V3 cam_z = mk(sv.cam[9], sv.cam[10], sv.cam[11]);
+    const float focal_length = len(sub(cam_p, mk(0, 0, 0.2f))); /* ray.cpp:1198 */
+    const float aperture = 0.1f;                                /* ray.cpp:1199 */
+
+    /* path state */
+    int ps = PS_NEED_JOB;
+    uint32_t rng = 0, job_index = 0;
+    int jx0 = 0, jx1 = 0, jy1 = 0, px = 0, py = 0;
+    uint32_t spp = 0, sample = 0;
+    float *dst = nullptr; /* where this job's pixels go (image or a partial plane) */
+    V3 color = mk(0, 0, 0), focal = mk(0, 0, 0);
+    V3 org = mk(0, 0, 0), dir = mk(0, 0, 0), wo = mk(0, 0, 0), weight = mk(1, 1, 1);
+    V3 surf_n = mk(0, 0, 0), prev_dir = mk(0, 0, 0);
+    uint32_t surf_mat = 0;
+    bool primary = true;
+
+    /* traversal state */
+    bool tracing = false;
+    uint32_t cur = 0;
+    int sp = 0;
+    float best_t = 0;
+    V3 hit_n = mk(0, 0, 0), inv_d = mk(0, 0, 0);
+    uint32_t hit_prim = kNoPrim;
+
+    unsigned long long c_paths = 0, c_rays = 0, c_nodes = 0, c_tris = 0, c_analytic = 0, c_fallback = 0;
+
+    for (;;) {
+        /* ---------------- produce the next ray (or run out of work) ---------------- */
+        if (!tracing) {
+            while (ps != PS_DONE) {
+                if (ps == PS_NEED_JOB) {
+                    unsigned long long j = ORT_NEXT_JOB(rv.next_job);
+                    if (j >= rv.job_count) { ps = PS_DONE; break; }
+                    if (rv.mode == JOBS_EXPLICIT) {
+                        ort_tile_job jb = rv.jobs[j];
+                        job_index = (uint32_t)j;
+                        jx0 = jb.x0; jx1 = jb.x1; jy1 = jb.y1;
+                        px = jb.x0; py = jb.y0;
+                        rng = jb.rng_state; spp = jb.spp;
+                        dst = rv.out;
+                        if (jb.x1 <= jb.x0 || jb.y1 <= jb.y0) { /* empty rect: the reference loops zero times */
+                            if (rv.final_states) rv.final_states[job_index] = rng;
+                            continue;
+                        }
+                    } else {
+                        /* implicit job space: [chunk k][my 8x8 block b][pixel-in-block p] */
+                        unsigned long long per_chunk = (unsigned long long)rv.my_blocks * 64ull;
+                        uint32_t k = (uint32_t)(j / per_chunk);
+                        uint32_t rem = (uint32_t)(j % per_chunk);
+                        uint32_t blk = rv.shard_index + (rem >> 6) * rv.shard_count;
+                        uint32_t pin = rem & 63u;
+                        int x = (int)((blk % rv.blocks_w) * 8u + (pin & 7u));
+                        int y = (int)((blk / rv.blocks_w) * 8u + (pin >> 3));
+                        if (x < rv.x0 || x >= rv.x1 || y < rv.y0 || y >= rv.y1) continue;
+                        uint32_t pix = (uint32_t)(y * rv.W + x);
+                        jx0 = x; jx1 = x + 1; jy1 = y + 1; px = x; py = y;
+                        if (rv.mode == JOBS_PIXEL) {
+                            rng = job_seed(rv.seed, pix);
+                            spp = rv.spp;
+                            dst = rv.out;
+                        } else {
+                            rng = job_seed(rv.seed, k * (uint32_t)(rv.W * rv.H) + pix);
+                            spp = rv.chunk;
+                            dst = rv.partial + (size_t)k * (size_t)rv.W * (size_t)rv.H * 3u;
+                        }
+                    }
+                    ps = PS_PIXEL;
+                }
+                if (ps == PS_PIXEL) {
+                    /* ray.cpp:1211-1221 */
+                    ORT_SIM_PIXEL_HOOK(px, py, rng);
+                    color = mk(0, 0, 0);
+                    float fx = (2.0f * px / (float)rv.W) - 1.0f;
+                    float fy = (2.0f * py / (float)rv.H) - 1.0f;
+                    V3 to_pixel = normalize(sub(add(scale(fx, cam_x), scale(fy, cam_y)), cam_z));
+                    focal = add(cam_p, scale(focal_length, to_pixel));
+                    sample = 0;
+                    ps = PS_SAMPLE;
+                }
+                if (ps == PS_HIT) {
+                    /* a traversal has finished: ray.cpp:817 then :1251-1277 (primary) or :1355-1421 (bounce) */
+                    bool alive = true;
+                    /* the reference only sees a shape through the node boxes above it (ray.cpp:788-803) */
+                    if (hit_prim != kNoPrim && !chain_admits(sv, hit_prim, org, dir)) {
+                        if (COUNTERS) c_fallback++;
+                        ref_raycast<COUNTERS>(sv, org, dir, lds_stack, spill, tid, best_t, hit_n, hit_prim, c_nodes, c_tris, c_analytic);
+                    }
+                    uint32_t hit_mat = 0;
+                    if (hit_prim != kNoPrim) {
+                        uint32_t hk = hit_prim >> 28, hs = hit_prim & 0x00ffffffu;
+                        hit_mat = (hk == PRIM_TRI) ? sv.tri_mat[hs] : (hk == PRIM_SPHERE) ? sv.sphere_mat[hs]
+                                : (hk == PRIM_BOX) ? sv.box_mat[hs] : sv.cyl_mat[hs];
+                    }
+                    V3 n = normalize(hit_n);
+                    ORT_SIM_RAY_HOOK(px, py, org, dir, best_t, n, hit_mat);
+                    if (primary) {
+                        if (COUNTERS) c_paths++;
+                        if (hit_mat) {
+                            Mat m = load_mat(sv.materials, hit_mat);
+                            if (m.is_light) {
+                                color = add(color, m.emit);
+                                alive = false;
+                            } else {
+                                org = add(org, scale(best_t - kEps, dir));
+                                surf_n = n;
+                                surf_mat = hit_mat;
+                                prev_dir = dir;
+                                if (len2(m.kd) > 0.0f) weight = had(weight, m.kd);
+                            }
+                        } else {
+                            alive = false; /* reference: undefined behaviour on a primary miss; defined: terminate */
+                        }
+                        primary = false;
+                    } else {
+                        if (hit_mat) {
+                            Mat m = load_mat(sv.materials, hit_mat);
+                            if (m.is_light) {
+                                V3 c = had(weight, m.emit);
+                                if (!isnan3(c) && !isinf3(c)) color = add(color, c);
+                                alive = false;
+                            } else {
+                                float p = pdf_brdf(n, dir, wo, kRoughness, m) * rv.rr;
+                                if (p > 0.000001f) {
+                                    V3 f = eval_scattering(n, dir, wo, m, kRoughness, best_t);
+                                    weight = had(divs(f, p), weight);
+                                }
+                                org = add(org, scale(best_t - kEps, dir));
+                                surf_n = n;
+                                surf_mat = hit_mat;
+                                prev_dir = dir;
+                                wo = neg(dir);
+                            }
+                        } else {
+                            alive = false;
+                        }
+                    }
+                    /* ray.cpp:1280: the roulette draw happens only while the path is alive */
+                    if (alive && rng_01(rng) < rv.rr) {
+                        /* sample_random_lights (ray.cpp:537-601): result unused, RNG advances */
+                        rng_step(rng);
+                        if (sv.light_count) {
+                            uint32_t li = rng % sv.light_count;
+                            if (sv.light_is_sphere[li]) { rng_step(rng); rng_step(rng); rng_step(rng); rng_step(rng); }
+                        }
+                        Mat sm = load_mat(sv.materials, surf_mat);
+                        bool is_trans;
+                        V3 wi = sample_brdf(rng, surf_n, wo, kRoughness, sm, is_trans);
+                        if (is_trans) org = add(org, scale(2.0f * kEps, prev_dir)); /* ray.cpp:1345-1348 */
+                        dir = wi;
+                        tracing = true;
+                        break;
+                    }
+                    sample++;
+                    ps = PS_SAMPLE;
+                }
+                if (ps == PS_SAMPLE) {
+                    if (sample == spp) {
+                        /* ray.cpp:1428 */
+                        V3 o = divs(color, (float)spp);
+                        float *p = dst + 3u * ((size_t)py * (size_t)rv.W + (size_t)px);
+                        p[0] = o.x; p[1] = o.y; p[2] = o.z;
+                        px++;
+                        if (px == jx1) { px = jx0; py++; }
+                        if (py == jy1) {
+                            if (rv.mode == JOBS_EXPLICIT && rv.final_states) rv.final_states[job_index] = rng;
+                            ps = PS_NEED_JOB;
+                        } else {
+                            ps = PS_PIXEL;
+                        }
+                        continue;
+                    }
+                    /* ray.cpp:1232-1246 */
+                    float rad = rng_between(rng, 0.0f, 2 * kPi);
+                    V3 ap = sub(add(add(cam_p, scale(aperture * ort_cosf(rad), cam_x)), scale(aperture * ort_sinf(rad), cam_y)),
+                                scale(0.1f, cam_z));
+                    dir = normalize(sub(focal, ap));
+                    wo = neg(normalize(dir));
+                    org = ap;
+                    weight = mk(1, 1, 1);
+                    surf_mat = 0;
+                    primary = true;
+                    tracing = true;
+                    break;
+                }
+            }
+            if (tracing) {
+                /* raycast_top_most_node (ray.cpp:1165-1176): start at the root */
+                ps = PS_HIT;
+                cur = 0;
+                sp = 0;
+                best_t = 3.402823466e+38f; /* Flt_Max, ray.cpp:627 */
+                hit_n = mk(0, 0, 0);
+                hit_prim = kNoPrim;
+                inv_d = mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+                if (COUNTERS) c_rays++;
+            }
+        }
+        if (ORT_BALLOT(ps != PS_DONE) == 0ull) break;
+
+        /* ---------------- closest hit: interruptible ordered DFS ---------------- */
+        while (tracing) {
+            if (!(cur & LEAF_BIT)) {
+                const float4 *np = sv.nodes + 4u * cur;
+                float4 a = np[0], b = np[1], c = np[2], d = np[3];
+                uint32_t c0 = om_f32_bits(d.x), c1 = om_f32_bits(d.y);
+                if (COUNTERS) c_nodes += 2;
+                /* conservative slab tests (same (p - o) * 1/d form as ray.cpp:215-222) */
+                float t0x = (a.x - org.x) * inv_d.x, t1x = (a.w - org.x) * inv_d.x;
+                float t0y = (a.y - org.y) * inv_d.y, t1y = (b.x - org.y) * inv_d.y;
+                float t0z = (a.z - org.z) * inv_d.z, t1z = (b.y - org.z) * inv_d.z;
+                float n0 = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
+                float f0 = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
+                float u0x = (b.z - org.x) * inv_d.x, u1x = (c.y - org.x) * inv_d.x;
+                float u0y = (b.w - org.y) * inv_d.y, u1y = (c.z - org.y) * inv_d.y;
+                float u0z = (c.x - org.z) * inv_d.z, u1z = (c.w - org.z) * inv_d.z;
+                float n1 = fmaxf(fmaxf(fminf(u0x, u1x), fminf(u0y, u1y)), fminf(u0z, u1z));
+                float f1 = fminf(fminf(fmaxf(u0x, u1x), fmaxf(u0y, u1y)), fmaxf(u0z, u1z));
+                bool h0 = (f0 * 1.0000004f >= n0) && (f0 >= 0.0f) && (n0 * 0.9999996f < best_t);
+                bool h1 = (f1 * 1.0000004f >= n1) && (f1 >= 0.0f) && (n1 * 0.9999996f < best_t) && (c1 != EMPTY_CHILD);
+                if (h0 && h1) {
+                    bool swap = n1 < n0;
+                    uint32_t nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
+                    if (sp < kLdsStack) lds_stack[sp * kBlock + tid] = farc;
+                    else spill[sp - kLdsStack] = farc;
+                    sp++;
+                    cur = nearc;
+                } else if (h0) {
+                    cur = c0;
+                } else if (h1) {
+                    cur = c1;
+                } else {
+                    if (sp == 0) { tracing = false; }
+                    else {
+                        sp--;
+                        cur = (sp < kLdsStack) ? lds_stack[sp * kBlock + tid] : spill[sp - kLdsStack];
+                    }
+                }
+            } else {
+                uint32_t kind = (cur >> 28) & 7u, count = ((cur >> 24) & 15u) + 1u, first = cur & 0x00ffffffu;
+                for (uint32_t i = 0; i < count; ++i)
+                    test_prim<COUNTERS>(sv, kind, first + i, org, dir, best_t, hit_n, hit_prim, c_tris, c_analytic);
+                if (sp == 0) { tracing = false; }
+                else {
+                    sp--;
+                    cur = (sp < kLdsStack) ? lds_stack[sp * kBlock + tid] : spill[sp - kLdsStack];
+                }
+            }
+            /* when most of the wave has finished its ray, let the finished lanes shade and refill */
+            if (ORT_POPC64(ORT_BALLOT(tracing)) < 40) break;
+        }
+    }
+
+    if (COUNTERS) {
+        ORT_COUNT(rv.counters + 0, c_paths);
+        ORT_COUNT(rv.counters + 1, c_rays);
+        ORT_COUNT(rv.counters + 2, c_nodes);
+        ORT_COUNT(rv.counters + 3, c_tris);
+        ORT_COUNT(rv.counters + 4, c_analytic);
+        ORT_COUNT(rv.counters + 5, c_fallback);
+    }
+}
+
+/* pixel = (sum over k of partial[k], in k order) / nchunks for one pixel (CHUNK policy) */
+ORT_D void combine_pixel(const RenderView &rv, unsigned long long idx) {
+    uint32_t blk = rv.shard_index + (uint32_t)(idx >> 6) * rv.shard_count;
+    uint32_t pin = (uint32_t)(idx & 63ull);
+    int x = (int)((blk % rv.blocks_w) * 8u + (pin & 7u));
+    int y = (int)((blk / rv.blocks_w) * 8u + (pin >> 3));
+    if (x < rv.x0 || x >= rv.x1 || y < rv.y0 || y >= rv.y1) return;
+    size_t pix = (size_t)y * (size_t)rv.W + (size_t)x;
+    size_t plane = (size_t)rv.W * (size_t)rv.H * 3u;
+    V3 acc = mk(0, 0, 0);
+    for (uint32_t k = 0; k < rv.nchunks; ++k) {
+        const float *p = rv.partial + (size_t)k * plane + 3u * pix;
+        acc = add(acc, mk(p[0], p[1], p[2]));
+    }
+    acc = divs(acc, (float)rv.nchunks);
+    float *o = rv.out + 3u * pix;
+    o[0] = acc.x; o[1] = acc.y; o[2] = acc.z;
+}
+
+#ifndef ORT_HOST_SIM
+template <bool COUNTERS>
+__global__ void __launch_bounds__(kBlock) pt_persistent(SceneView sv, RenderView rv) {
+    __shared__ uint32_t lds_stack[kLdsStack * kBlock];
+    pt_lane<COUNTERS>(sv, rv, lds_stack, (int)threadIdx.x);
+}
+
+__global__ void combine_chunks(RenderView rv) {
+    unsigned long long idx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (unsigned long long)rv.my_blocks * 64ull) return;
+    combine_pixel(rv, idx);
+}
+
+/* ---- host side --------------------------------------------------------------------------- */
+#define ORT_HIP(call)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            *err = std::string(#call) + ": " + hipGetErrorString(e_);                          \
+            return ORT_ERR_HIP;                                                                \
+        }                                                                                      \
+    } while (0)
+
+int device_count(int *n, std::string *err) {
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { *n = 0; *err = std::string("hipGetDeviceCount: ") + hipGetErrorString(e); return ORT_ERR_NO_DEVICE; }
+    *n = c;
+    return ORT_OK;
+}
+
+template <typename T>
+static int upload_vec(const std::vector<T> &v, void **dst, std::string *err) {
+    size_t bytes = v.size() * sizeof(T);
+    ORT_HIP(hipMalloc(dst, bytes ? bytes : 16));
+    if (bytes) ORT_HIP(hipMemcpy(*dst, v.data(), bytes, hipMemcpyHostToDevice));
+    return ORT_OK;
+}
+
+void device_release(Scene *scene) {
+    DeviceScene *d = scene->dev;
+    if (!d) return;
+    (void)hipSetDevice(d->device);
+    void *ptrs[] = {d->nodes, d->tris, d->tri_mat, d->spheres, d->sphere_mat, d->boxes, d->box_mat, d->cyls, d->cyl_mat,
+                    d->materials, d->light_is_sphere, d->ref_nodes, d->ref_recs, d->chain_boxes, d->tri_chain, d->sphere_chain,
+                    d->box_chain, d->cyl_chain, d->ctrl, d->partial, d->staging, d->jobs, d->states};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    if (d->ev0) (void)hipEventDestroy(d->ev0);
+    if (d->ev1) (void)hipEventDestroy(d->ev1);
+    delete d;
+    scene->dev = nullptr;
+}
+
+int device_upload(Scene *scene, int device, std::string *err) {
+    int n = 0;
+    int rc = device_count(&n, err);
+    if (rc != ORT_OK) return rc;
+    if (n <= 0) { *err = "no HIP device visible"; return ORT_ERR_NO_DEVICE; }
+    if (device < 0 || device >= n) { *err = "device index out of range"; return ORT_ERR_INVALID; }
+    device_release(scene);
+    ORT_HIP(hipSetDevice(device));
+    DeviceScene *d = new DeviceScene();
+    d->device = device;
+    scene->dev = d;
+    const Tree &t = scene->tree;
+    if ((rc = upload_vec(t.nodes, &d->nodes, err))) return rc;
+    if ((rc = upload_vec(t.tris, &d->tris, err))) return rc;
+    if ((rc = upload_vec(t.tri_mat, &d->tri_mat, err))) return rc;
+    if ((rc = upload_vec(t.spheres, &d->spheres, err))) return rc;
+    if ((rc = upload_vec(t.sphere_mat, &d->sphere_mat, err))) return rc;
+    if ((rc = upload_vec(t.boxes, &d->boxes, err))) return rc;
+    if ((rc = upload_vec(t.box_mat, &d->box_mat, err))) return rc;
+    if ((rc = upload_vec(t.cyls, &d->cyls, err))) return rc;
+    if ((rc = upload_vec(t.cyl_mat, &d->cyl_mat, err))) return rc;
+    std::vector<DevMaterial> mats(scene->materials.size());
+    for (size_t i = 0; i < mats.size(); ++i) {
+        const ort_material &m = scene->materials[i];
+        DevMaterial dm{};
+        dm.diffuse[0] = m.diffuse.x; dm.diffuse[1] = m.diffuse.y; dm.diffuse[2] = m.diffuse.z; dm.ior = m.ior;
+        dm.specular[0] = m.specular[0]; dm.specular[1] = m.specular[1]; dm.specular[2] = m.specular[2];
+        dm.is_light = m.is_light ? 1u : 0u;
+        dm.transmission[0] = m.transmission.x; dm.transmission[1] = m.transmission.y; dm.transmission[2] = m.transmission.z;
+        dm.emit[0] = m.emit.x; dm.emit[1] = m.emit.y; dm.emit[2] = m.emit.z;
+        mats[i] = dm;
+    }
+    if ((rc = upload_vec(mats, &d->materials, err))) return rc;
+    std::vector<uint32_t> lis(scene->lights.size());
+    for (size_t i = 0; i < lis.size(); ++i) lis[i] = (scene->lights[i].type == 1u) ? 1u : 0u;
+    d->light_count = (uint32_t)lis.size();
+    if ((rc = upload_vec(lis, &d->light_is_sphere, err))) return rc;
+    const RefTree &rt = scene->ref;
+    if ((rc = upload_vec(rt.nodes, &d->ref_nodes, err))) return rc;
+    if ((rc = upload_vec(rt.recs, &d->ref_recs, err))) return rc;
+    if ((rc = upload_vec(rt.chain_boxes, &d->chain_boxes, err))) return rc;
+    if ((rc = upload_vec(rt.tri_chain, &d->tri_chain, err))) return rc;
+    if ((rc = upload_vec(rt.sphere_chain, &d->sphere_chain, err))) return rc;
+    if ((rc = upload_vec(rt.box_chain, &d->box_chain, err))) return rc;
+    if ((rc = upload_vec(rt.cyl_chain, &d->cyl_chain, err))) return rc;
+    ORT_HIP(hipMalloc((void **)&d->ctrl, 8 * sizeof(unsigned long long)));
+    ORT_HIP(hipMemset(d->ctrl, 0, 8 * sizeof(unsigned long long)));
+    ORT_HIP(hipEventCreate(&d->ev0));
+    ORT_HIP(hipEventCreate(&d->ev1));
+    hipDeviceProp_t prop;
+    ORT_HIP(hipGetDeviceProperties(&prop, device));
+    d->cu_count = prop.multiProcessorCount;
+    return ORT_OK;
+}
+
+uint64_t render_workspace_bytes(const ort_render_params *p) {
+    if (p->policy != ORT_POLICY_CHUNK || p->chunk == 0) return 0;
+    uint64_t nch = p->spp / p->chunk;
+    return nch * (uint64_t)p->width * (uint64_t)p->height * 12ull;
+}
+
+static int ensure(void **ptr, size_t *have, size_t need, std::string *err) {
+    if (*have >= need && *ptr) return ORT_OK;
+    if (*ptr) ORT_HIP(hipFree(*ptr));
+    *ptr = nullptr;
+    *have = 0;
+    ORT_HIP(hipMalloc(ptr, need ? need : 16));
+    *have = need;
+    return ORT_OK;
+}
+
+int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *jobs, uint32_t job_count, void *d_out,
+                  float *h_out, void *stream_v, uint32_t *final_states, ort_stats *stats, std::string *err) {
+    DeviceScene *d = scene->dev;
+    if (!d) { *err = "scene is not uploaded to a device (ort_scene_upload)"; return ORT_ERR_NO_DEVICE; }
+    ORT_HIP(hipSetDevice(d->device));
+    hipStream_t stream = (hipStream_t)stream_v;
+    const size_t image_bytes = (size_t)p->width * (size_t)p->height * 12u;
+    int rc;
+
+    float *out = (float *)d_out;
+    if (!out) {
+        if ((rc = ensure((void **)&d->staging, &d->staging_bytes, image_bytes, err))) return rc;
+        out = d->staging;
+        if (h_out) ORT_HIP(hipMemcpyAsync(out, h_out, image_bytes, hipMemcpyHostToDevice, stream));
+    }
+
+    SceneView sv{};
+    sv.nodes = (const float4 *)d->nodes; sv.tris = (const float4 *)d->tris; sv.tri_mat = (const uint32_t *)d->tri_mat;
+    sv.spheres = (const float4 *)d->spheres; sv.sphere_mat = (const uint32_t *)d->sphere_mat;
+    sv.boxes = (const float4 *)d->boxes; sv.box_mat = (const uint32_t *)d->box_mat;
+    sv.cyls = (const float4 *)d->cyls; sv.cyl_mat = (const uint32_t *)d->cyl_mat;
+    sv.materials = (const float4 *)d->materials;
+    sv.light_is_sphere = (const uint32_t *)d->light_is_sphere;
+    sv.light_count = d->light_count;
+    sv.ref_nodes = (const float4 *)d->ref_nodes; sv.ref_recs = (const uint32_t *)d->ref_recs;
+    sv.chain_boxes = (const float4 *)d->chain_boxes;
+    sv.tri_chain = (const uint32_t *)d->tri_chain; sv.sphere_chain = (const uint32_t *)d->sphere_chain;
+    sv.box_chain = (const uint32_t *)d->box_chain; sv.cyl_chain = (const uint32_t *)d->cyl_chain;
+    ort_camera cam;
+    camera_basis(*scene, p->width, p->height, &cam);
+    memcpy(sv.cam, &cam, sizeof(cam));
+
+    RenderView rv{};
+    rv.W = p->width; rv.H = p->height;
+    rv.x0 = p->x0; rv.y0 = p->y0; rv.x1 = p->x1; rv.y1 = p->y1;
+    rv.seed = p->seed; rv.spp = p->spp; rv.chunk = p->chunk; rv.rr = p->rr;
+    rv.out = out;
+    rv.next_job = d->ctrl;
+    rv.counters = d->ctrl + 1;
+    rv.shard_count = p->shard_count > 1 ? p->shard_count : 1;
+    rv.shard_index = p->shard_count > 1 ? p->shard_index : 0;
+    rv.blocks_w = (uint32_t)((p->width + 7) / 8);
+    uint32_t blocks_total = rv.blocks_w * (uint32_t)((p->height + 7) / 8);
+    rv.my_blocks = (blocks_total > rv.shard_index) ? (blocks_total - rv.shard_index + rv.shard_count - 1) / rv.shard_count : 0;
+
+    if (jobs) {
+        rv.mode = JOBS_EXPLICIT;
+        rv.job_count = job_count;
+        if ((rc = ensure(&d->jobs, &d->jobs_bytes, (size_t)job_count * sizeof(ort_tile_job), err))) return rc;
+        ORT_HIP(hipMemcpyAsync(d->jobs, jobs, (size_t)job_count * sizeof(ort_tile_job), hipMemcpyHostToDevice, stream));
+        rv.jobs = (const ort_tile_job *)d->jobs;
+        if (final_states) {
+            if ((rc = ensure(&d->states, &d->states_bytes, (size_t)job_count * 4u, err))) return rc;
+            rv.final_states = (uint32_t *)d->states;
+        }
+    } else if (p->policy == ORT_POLICY_PIXEL) {
+        rv.mode = JOBS_PIXEL;
+        rv.nchunks = 1;
+        rv.job_count = (unsigned long long)rv.my_blocks * 64ull;
+    } else {
+        rv.mode = JOBS_CHUNK;
+        rv.nchunks = p->spp / p->chunk;
+        rv.job_count = (unsigned long long)rv.my_blocks * 64ull * rv.nchunks;
+        size_t need = (size_t)rv.nchunks * image_bytes;
+        if ((rc = ensure((void **)&d->partial, &d->partial_bytes, need, err))) return rc;
+        rv.partial = d->partial;
+    }
+
+    const bool counters = (p->flags & ORT_RENDER_COUNTERS) != 0;
+    ORT_HIP(hipMemsetAsync(d->ctrl, 0, 8 * sizeof(unsigned long long), stream));
+    /* persistent grid: 4 blocks of 256 lanes per CU, never more lanes than jobs */
+    unsigned long long lanes_wanted = rv.job_count;
+    unsigned int max_blocks = (unsigned int)(d->cu_count > 0 ? d->cu_count : 256) * 4u;
+    unsigned int grid = (unsigned int)((lanes_wanted + kBlock - 1) / kBlock);
+    if (grid > max_blocks) grid = max_blocks;
+    if (grid == 0) grid = 1;
+    if (stats) ORT_HIP(hipEventRecord(d->ev0, stream));
+    if (counters) hipLaunchKernelGGL(pt_persistent<true>, dim3(grid), dim3(kBlock), 0, stream, sv, rv);
+    else hipLaunchKernelGGL(pt_persistent<false>, dim3(grid), dim3(kBlock), 0, stream, sv, rv);
+    ORT_HIP(hipGetLastError());
+    if (rv.mode == JOBS_CHUNK) {
+        unsigned long long total = (unsigned long long)rv.my_blocks * 64ull;
+        unsigned int cgrid = (unsigned int)((total + 255) / 256);
+        if (cgrid) hipLaunchKernelGGL(combine_chunks, dim3(cgrid), dim3(256), 0, stream, rv);
+        ORT_HIP(hipGetLastError());
+    }
+    if (stats) ORT_HIP(hipEventRecord(d->ev1, stream));
+
+    if (!d_out && h_out) ORT_HIP(hipMemcpyAsync(h_out, out, image_bytes, hipMemcpyDeviceToHost, stream));
+    if (final_states) ORT_HIP(hipMemcpyAsync(final_states, d->states, (size_t)job_count * 4u, hipMemcpyDeviceToHost, stream));
+    if (stats || !d_out || final_states) ORT_HIP(hipStreamSynchronize(stream));
+    if (stats) {
+        memset(stats, 0, sizeof(*stats));
+        float ms = 0;
+        ORT_HIP(hipEventElapsedTime(&ms, d->ev0, d->ev1));
+        stats->kernel_ms = ms;
+        if (counters) {
+            unsigned long long c[6];
+            ORT_HIP(hipMemcpy(c, d->ctrl + 1, sizeof(c), hipMemcpyDeviceToHost));
+            stats->paths = c[0]; stats->rays = c[1]; stats->node_tests = c[2]; stats->tri_tests = c[3]; stats->analytic_tests = c[4];
+            stats->fallback_rays = c[5];
+        }
+    }
+    return ORT_OK;
+}
+
+#endif /* !ORT_HOST_SIM */
+
+} // namespace ort

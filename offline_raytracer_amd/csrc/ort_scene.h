@@ -1,0 +1,157 @@
+/*
+ * ort_scene.h -- host-side scene object behind the opaque ort_scene handle.
+ */
+#ifndef ORT_SCENE_H
+#define ORT_SCENE_H
+
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/ort.h"
+
+namespace ort {
+
+struct HostMesh {
+    std::vector<float> vertices;   // 3 * n, world space after placement
+    std::vector<uint32_t> indices; // 3 * triangles
+    uint32_t mat = 0;
+    ort_v3 aabb_min = {0, 0, 0}, aabb_max = {0, 0, 0};
+};
+
+/* ---- device-resident layout (mirrored on the host before upload) -----------------------
+ * All records are 16-byte multiples so one lane fetches a record with dwordx4 loads.
+ *
+ * Node (64 B): a binary node carrying BOTH children's boxes, so one fetch decides both.
+ *   lo0.xyz hi0.xyz lo1.xyz hi1.xyz child0 child1 pad pad
+ * child word: bit31 = leaf.  interior: node index.  leaf: [30:28] primitive kind,
+ *   [27:24] count-1, [23:0] first primitive index within that kind's array.
+ */
+struct DevNode {
+    float lo0[3], hi0[3], lo1[3], hi1[3];
+    uint32_t child0, child1, pad0, pad1;
+};
+static_assert(sizeof(DevNode) == 64, "node record must be 64 B");
+
+enum : uint32_t { PRIM_TRI = 0, PRIM_SPHERE = 1, PRIM_BOX = 2, PRIM_CYL = 3 };
+constexpr uint32_t LEAF_BIT = 0x80000000u;
+constexpr uint32_t EMPTY_CHILD = 0xffffffffu; /* leaf, kind 7: never visited (box is inverted) */
+constexpr uint32_t MAX_LEAF_PRIMS = 16;
+
+inline uint32_t make_leaf(uint32_t kind, uint32_t first, uint32_t count) {
+    return LEAF_BIT | (kind << 28) | ((count - 1u) << 24) | (first & 0x00ffffffu);
+}
+
+/* Triangle slab (48 B): v0, e1 = v1 - v0, e2 = v2 - v0, n = cross(e1, e2).  e1/e2/n are the
+   reference's own f32 expressions (ray.cpp:87-88,110) evaluated once on the host: same
+   bits as evaluating them per test. */
+struct DevTri { float v0[3], e1[3], e2[3], n[3]; };
+static_assert(sizeof(DevTri) == 48, "triangle slab must be 48 B");
+
+struct DevSphere { float c[3]; float r; };                     /* 16 B */
+struct DevBox { float lo[3]; float pad0; float hi[3]; float pad1; }; /* 32 B */
+/* cylinder: base, radius, the row-major rotation of rotation_matrix_along_z(axis)
+   (ray.cpp:8-33) and |axis| (ray.cpp:302), all precomputed with the reference's f32
+   expressions; 64 B */
+struct DevCyl { float base[3]; float r; float rot[9]; float len; float pad[2]; };
+static_assert(sizeof(DevCyl) == 64, "cylinder record must be 64 B");
+
+/* material as the path reads it (ray.h:30-40 minus specular.w), 64 B */
+struct DevMaterial {
+    float diffuse[3]; float ior;
+    float specular[3]; uint32_t is_light;
+    float transmission[3]; float pad0;
+    float emit[3]; float pad1;
+};
+static_assert(sizeof(DevMaterial) == 64, "material record must be 64 B");
+
+struct Tree {
+    std::vector<DevNode> nodes;
+    std::vector<DevTri> tris;
+    std::vector<uint32_t> tri_mat;
+    std::vector<DevSphere> spheres;
+    std::vector<uint32_t> sphere_mat;
+    std::vector<DevBox> boxes;
+    std::vector<uint32_t> box_mat;
+    std::vector<DevCyl> cyls;
+    std::vector<uint32_t> cyl_mat;
+    /* source index -> slot in the reordered arrays above (triangles: mesh-major triangle id) */
+    std::vector<uint32_t> tri_slot, sphere_slot, box_slot, cyl_slot;
+    uint32_t leaf_count = 0, max_leaf_prims = 0, max_depth = 0;
+    float sah_cost = 0;
+    bool built = false;
+};
+
+/* ---- the reference-compatible loose octree (ort_reftree.cpp) ---------------------------
+ * Node (48 B): lo.xyz first_child | hi.xyz rec_first | rec_count flags pad pad
+ * flags: bit0 = is_leaf, bit1 = the reference's push buffer is non-empty.
+ * recs: kind << 28 | slot (same slots as the fast tree's primitive arrays).
+ * chain_boxes: per record-holding node, the boxes of that node and its ancestors up to,
+ * not including, the root (2 x F4 each); *_chain[slot] = len << 28 | first pair index. */
+struct F4 { float x, y, z, w; };
+struct DevRefNode {
+    float lo[3]; int32_t first_child;
+    float hi[3]; uint32_t rec_first;
+    uint32_t rec_count, flags, pad0, pad1;
+};
+static_assert(sizeof(DevRefNode) == 48, "reference octree node must be 48 B");
+
+struct RefTree {
+    std::vector<DevRefNode> nodes;
+    std::vector<uint32_t> recs;
+    std::vector<F4> chain_boxes;
+    std::vector<uint32_t> tri_chain, sphere_chain, box_chain, cyl_chain;
+    uint32_t nonempty_leaves = 0, max_leaf_records = 0;
+    bool built = false;
+};
+
+struct DeviceScene; /* ort_kernels.hip */
+
+struct Scene {
+    std::vector<ort_material> materials;
+    std::vector<ort_sphere> spheres;
+    std::vector<ort_box> boxes;
+    std::vector<ort_cylinder> cylinders;
+    std::vector<ort_light> lights;
+    std::vector<HostMesh> meshes;
+    ort_v3 ambient = {0, 0, 0};
+    ort_v3 camera_p = {0, 0, 0};
+    float camera_quat[4] = {0, 0, 0, 1}; /* xyzw */
+    float camera_height_ratio = 0;
+    int32_t screen_width = 0, screen_height = 0;
+
+    /* main() inserts one inert CSG shape into its octree (macos_main.mm:322-332,532-538); it can
+       never be hit but it shapes the node boxes, so scenes loaded from .scn carry it */
+    bool reference_csg = false;
+
+    Tree tree;
+    RefTree ref;
+    DeviceScene *dev = nullptr;
+};
+
+/* ort_parse.cpp */
+int parse_scn_text(const char *text, size_t size, const char *base_dir, Scene *scene, std::string *err);
+int read_file(const char *path, std::vector<char> *out);
+void camera_basis(const Scene &s, int32_t width, int32_t height, ort_camera *out);
+
+/* ort_tree.cpp */
+int build_tree(Scene *scene, std::string *err);
+/* ort_reftree.cpp */
+int build_ref_tree(Scene *scene, std::string *err);
+
+/* ort_hdr.cpp */
+uint32_t rgbe_pack(float r, float g, float b);
+
+/* ort_kernels.hip */
+int device_count(int *n, std::string *err);
+int device_upload(Scene *scene, int device, std::string *err);
+void device_release(Scene *scene);
+int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *jobs, uint32_t job_count,
+                  void *d_out, float *h_out, void *stream, uint32_t *final_states, ort_stats *stats, std::string *err);
+uint64_t render_workspace_bytes(const ort_render_params *p);
+
+} // namespace ort
+
+struct ort_scene : public ort::Scene {};
+
+#endif

@@ -1,0 +1,395 @@
+/*
+ * ort_tree.cpp -- builds the GPU acceleration structure on the host.
+ *
+ * Replaces the loose-octree construction of the reference (code/macos_main.mm:418-545
+ * driving code/ray.cpp:1799-2045).  raycast_bvh (ray.cpp:624-822) returns the minimum-t
+ * hit over all shapes whose node chain passes a conservative test, so ANY conservative
+ * hierarchy yields the same (t, normal, material) up to bit-equal-t ties.
+ * This one is laid out for divergent per-lane fetches on gfx950: 64-byte nodes that
+ * carry both children's boxes, primitives reordered so that every leaf is a contiguous
+ * run of 16-byte-aligned records of one kind, split by binned SAH.
+ */
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <float.h>
+
+#include "ort_scene.h"
+
+namespace ort {
+
+namespace {
+
+struct Box3 {
+    float lo[3], hi[3];
+    void reset() {
+        for (int k = 0; k < 3; ++k) { lo[k] = FLT_MAX; hi[k] = -FLT_MAX; }
+    }
+    void grow(const Box3 &b) {
+        for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], b.lo[k]); hi[k] = std::max(hi[k], b.hi[k]); }
+    }
+    void grow_point(const float p[3]) {
+        for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], p[k]); hi[k] = std::max(hi[k], p[k]); }
+    }
+    float half_area() const {
+        float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        if (dx < 0 || dy < 0 || dz < 0) return 0.0f;
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+
+struct Prim {
+    uint32_t kind, index; /* index into the scene's source arrays (triangles: global id) */
+    Box3 box;
+    float centroid[3];
+};
+
+struct TriRef { uint32_t mesh, k; };
+
+/* the reference's vector expressions, kept op-for-op so precomputed values carry the same bits */
+inline void v_sub(const float a[3], const float b[3], float r[3]) { r[0] = a[0] - b[0]; r[1] = a[1] - b[1]; r[2] = a[2] - b[2]; }
+inline void v_cross(const float a[3], const float b[3], float r[3]) { /* math.h:280-290 */
+    r[0] = a[1] * b[2] - b[1] * a[2];
+    r[1] = b[0] * a[2] - a[0] * b[2];
+    r[2] = a[0] * b[1] - b[0] * a[1];
+}
+inline float v_len(const float a[3]) { return sqrtf(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]); } /* math.h:173-177 */
+inline bool near0(float v) { return v >= -0.000001f && v < 0.000001f; }
+inline bool v_is0(const float a[3]) { return near0(a[0]) && near0(a[1]) && near0(a[2]); }       /* math.h:331-345 */
+inline void v_normalize(const float a[3], float r[3]) {                                         /* math.h:298-310 */
+    float l = v_len(a);
+    float diff = l - 0.0f;
+    if (!(diff >= -0.000001f && diff < 0.000001f)) { r[0] = a[0] / l; r[1] = a[1] / l; r[2] = a[2] / l; }
+    else { r[0] = r[1] = r[2] = 0.0f; }
+}
+
+/* rotation_matrix_along_z (ray.cpp:8-33), rows b, c, a */
+void cylinder_frame(const ort_cylinder &c, float rot[9], float *len) {
+    const float z[3] = {0, 0, 1}, x[3] = {1, 0, 0};
+    float axis[3] = {c.axis.x, c.axis.y, c.axis.z};
+    float id[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    memcpy(rot, id, sizeof(id));
+    float cr[3];
+    v_cross(axis, z, cr);
+    if (!v_is0(cr)) {
+        float a[3], b[3], t[3], cc[3];
+        v_normalize(axis, a);
+        v_cross(z, a, t);
+        v_normalize(t, b);
+        if (v_is0(b)) { v_cross(x, a, t); v_normalize(t, b); }
+        v_cross(a, b, cc);
+        memcpy(rot + 0, b, 12); memcpy(rot + 3, cc, 12); memcpy(rot + 6, a, 12);
+    }
+    *len = v_len(axis); /* ray.cpp:302 */
+}
+
+/* pad a primitive's box by a few ulps of its coordinates so the node test stays conservative */
+void pad_box(Box3 *b) {
+    for (int k = 0; k < 3; ++k) {
+        float m = std::max(fabsf(b->lo[k]), fabsf(b->hi[k]));
+        float pad = 4e-7f * m + 1e-7f;
+        b->lo[k] -= pad;
+        b->hi[k] += pad;
+    }
+}
+
+struct Builder {
+    Scene *scene;
+    std::vector<Prim> prims;
+    std::vector<TriRef> tri_refs;
+    Tree *tree;
+    static constexpr int kBins = 16;
+    static constexpr uint32_t kMaxLeafTri = 4;
+    static constexpr uint32_t kMaxLeafOther = 2;
+    static constexpr uint32_t kDepthBudget = 60; /* traversal stack holds 64 entries */
+    static constexpr float kNodeCost = 1.0f, kPrimCost = 1.2f;
+    double sah_sum = 0;
+    float root_area = 1;
+
+    static uint32_t log2_ceil(uint32_t n) {
+        uint32_t l = 0;
+        while ((1u << l) < n) ++l;
+        return l;
+    }
+
+    uint32_t emit_leaf(uint32_t begin, uint32_t end) {
+        uint32_t kind = prims[begin].kind, count = end - begin, first = 0;
+        switch (kind) {
+        case PRIM_TRI:
+            first = (uint32_t)tree->tris.size();
+            for (uint32_t i = begin; i < end; ++i) {
+                const TriRef &tr = tri_refs[prims[i].index];
+                const HostMesh &m = scene->meshes[tr.mesh];
+                const float *v0 = &m.vertices[3 * (size_t)m.indices[tr.k]];
+                const float *v1 = &m.vertices[3 * (size_t)m.indices[tr.k + 1]];
+                const float *v2 = &m.vertices[3 * (size_t)m.indices[tr.k + 2]];
+                DevTri t;
+                memcpy(t.v0, v0, 12);
+                v_sub(v1, v0, t.e1); /* ray.cpp:87 */
+                v_sub(v2, v0, t.e2); /* ray.cpp:88 */
+                v_cross(t.e1, t.e2, t.n); /* ray.cpp:110 */
+                tree->tri_slot[prims[i].index] = (uint32_t)tree->tris.size();
+                tree->tris.push_back(t);
+                tree->tri_mat.push_back(m.mat);
+            }
+            break;
+        case PRIM_SPHERE:
+            first = (uint32_t)tree->spheres.size();
+            for (uint32_t i = begin; i < end; ++i) {
+                const ort_sphere &s = scene->spheres[prims[i].index];
+                tree->sphere_slot[prims[i].index] = (uint32_t)tree->spheres.size();
+                tree->spheres.push_back(DevSphere{{s.center.x, s.center.y, s.center.z}, s.r});
+                tree->sphere_mat.push_back(s.mat);
+            }
+            break;
+        case PRIM_BOX:
+            first = (uint32_t)tree->boxes.size();
+            for (uint32_t i = begin; i < end; ++i) {
+                const ort_box &b = scene->boxes[prims[i].index];
+                tree->box_slot[prims[i].index] = (uint32_t)tree->boxes.size();
+                tree->boxes.push_back(DevBox{{b.min.x, b.min.y, b.min.z}, 0, {b.max.x, b.max.y, b.max.z}, 0});
+                tree->box_mat.push_back(b.mat);
+            }
+            break;
+        default:
+            first = (uint32_t)tree->cyls.size();
+            for (uint32_t i = begin; i < end; ++i) {
+                const ort_cylinder &c = scene->cylinders[prims[i].index];
+                DevCyl d{};
+                d.base[0] = c.base.x; d.base[1] = c.base.y; d.base[2] = c.base.z;
+                d.r = c.r;
+                cylinder_frame(c, d.rot, &d.len);
+                tree->cyl_slot[prims[i].index] = (uint32_t)tree->cyls.size();
+                tree->cyls.push_back(d);
+                tree->cyl_mat.push_back(c.mat);
+            }
+            break;
+        }
+        tree->leaf_count++;
+        tree->max_leaf_prims = std::max(tree->max_leaf_prims, count);
+        return make_leaf(kind, first, count);
+    }
+
+    Box3 bounds(uint32_t begin, uint32_t end) const {
+        Box3 b;
+        b.reset();
+        for (uint32_t i = begin; i < end; ++i) b.grow(prims[i].box);
+        return b;
+    }
+
+    bool homogeneous(uint32_t begin, uint32_t end) const {
+        for (uint32_t i = begin + 1; i < end; ++i)
+            if (prims[i].kind != prims[begin].kind) return false;
+        return true;
+    }
+
+    /* returns the child word for prims [begin,end); box = their bounds */
+    uint32_t build(uint32_t begin, uint32_t end, const Box3 &box, uint32_t depth) {
+        tree->max_depth = std::max(tree->max_depth, depth);
+        uint32_t count = end - begin;
+        bool same_kind = homogeneous(begin, end);
+        uint32_t max_leaf = (prims[begin].kind == PRIM_TRI) ? kMaxLeafTri : kMaxLeafOther;
+        bool out_of_depth = depth >= kDepthBudget;
+        if (same_kind && (count == 1 || (out_of_depth && count <= MAX_LEAF_PRIMS))) {
+            sah_sum += (double)kPrimCost * count * box.half_area();
+            return emit_leaf(begin, end);
+        }
+
+        uint32_t mid = begin;
+        bool have_split = false;
+        bool force_median = (depth + log2_ceil(count) + 2 >= kDepthBudget);
+        if (!same_kind && count <= max_leaf) {
+            /* small mixed group: separate the first kind from the rest */
+            uint32_t k0 = prims[begin].kind;
+            mid = (uint32_t)(std::partition(prims.begin() + begin, prims.begin() + end,
+                                            [&](const Prim &p) { return p.kind == k0; }) - prims.begin());
+            have_split = (mid > begin && mid < end);
+        }
+        if (!have_split && !force_median) {
+            Box3 cb;
+            cb.reset();
+            for (uint32_t i = begin; i < end; ++i) cb.grow_point(prims[i].centroid);
+            float best_cost = FLT_MAX;
+            int best_axis = -1, best_bin = -1;
+            for (int axis = 0; axis < 3; ++axis) {
+                float extent = cb.hi[axis] - cb.lo[axis];
+                if (!(extent > 0)) continue;
+                Box3 bin_box[kBins];
+                uint32_t bin_n[kBins];
+                for (int b = 0; b < kBins; ++b) { bin_box[b].reset(); bin_n[b] = 0; }
+                float scale = kBins / extent;
+                for (uint32_t i = begin; i < end; ++i) {
+                    int b = (int)((prims[i].centroid[axis] - cb.lo[axis]) * scale);
+                    b = std::max(0, std::min(kBins - 1, b));
+                    bin_box[b].grow(prims[i].box);
+                    bin_n[b]++;
+                }
+                float right_area[kBins];
+                uint32_t right_n[kBins];
+                Box3 acc;
+                acc.reset();
+                uint32_t n = 0;
+                for (int b = kBins - 1; b > 0; --b) {
+                    acc.grow(bin_box[b]);
+                    n += bin_n[b];
+                    right_area[b] = acc.half_area();
+                    right_n[b] = n;
+                }
+                acc.reset();
+                n = 0;
+                for (int b = 0; b < kBins - 1; ++b) {
+                    acc.grow(bin_box[b]);
+                    n += bin_n[b];
+                    if (n == 0 || right_n[b + 1] == 0) continue;
+                    float cost = acc.half_area() * n + right_area[b + 1] * right_n[b + 1];
+                    if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = b; }
+                }
+            }
+            if (best_axis >= 0) {
+                float area = std::max(box.half_area(), 1e-30f);
+                float split_cost = kNodeCost + kPrimCost * best_cost / area;
+                float leaf_cost = kPrimCost * count;
+                if (same_kind && count <= max_leaf && leaf_cost <= split_cost) {
+                    sah_sum += (double)kPrimCost * count * box.half_area();
+                    return emit_leaf(begin, end);
+                }
+                float lo = cb.lo[best_axis], scale = kBins / (cb.hi[best_axis] - cb.lo[best_axis]);
+                mid = (uint32_t)(std::partition(prims.begin() + begin, prims.begin() + end, [&](const Prim &p) {
+                          int b = (int)((p.centroid[best_axis] - lo) * scale);
+                          b = std::max(0, std::min(kBins - 1, b));
+                          return b <= best_bin;
+                      }) - prims.begin());
+                have_split = (mid > begin && mid < end);
+            } else if (same_kind && count <= max_leaf) {
+                sah_sum += (double)kPrimCost * count * box.half_area();
+                return emit_leaf(begin, end);
+            }
+        }
+        if (!have_split) {
+            /* object median along the widest box axis (also the balanced fallback near the depth budget) */
+            int axis = 0;
+            float ext[3] = {box.hi[0] - box.lo[0], box.hi[1] - box.lo[1], box.hi[2] - box.lo[2]};
+            if (ext[1] > ext[axis]) axis = 1;
+            if (ext[2] > ext[axis]) axis = 2;
+            mid = begin + count / 2;
+            std::nth_element(prims.begin() + begin, prims.begin() + mid, prims.begin() + end,
+                             [axis](const Prim &a, const Prim &b) { return a.centroid[axis] < b.centroid[axis]; });
+        }
+
+        uint32_t node_index = (uint32_t)tree->nodes.size();
+        tree->nodes.push_back(DevNode{});
+        sah_sum += (double)kNodeCost * box.half_area();
+        Box3 lb = bounds(begin, mid), rb = bounds(mid, end);
+        uint32_t c0 = build(begin, mid, lb, depth + 1);
+        uint32_t c1 = build(mid, end, rb, depth + 1);
+        DevNode &n = tree->nodes[node_index];
+        memcpy(n.lo0, lb.lo, 12); memcpy(n.hi0, lb.hi, 12);
+        memcpy(n.lo1, rb.lo, 12); memcpy(n.hi1, rb.hi, 12);
+        n.child0 = c0; n.child1 = c1;
+        return node_index;
+    }
+};
+
+} // namespace
+
+int build_tree(Scene *scene, std::string *err) {
+    Tree fresh;
+    scene->tree = fresh;
+    Tree *tree = &scene->tree;
+    Builder b;
+    b.scene = scene;
+    b.tree = tree;
+
+    for (uint32_t mi = 0; mi < scene->meshes.size(); ++mi) {
+        const HostMesh &m = scene->meshes[mi];
+        for (uint32_t k = 0; k + 2 < m.indices.size(); k += 3) {
+            Prim p;
+            p.kind = PRIM_TRI;
+            p.index = (uint32_t)b.tri_refs.size();
+            b.tri_refs.push_back(TriRef{mi, k});
+            p.box.reset();
+            for (int c = 0; c < 3; ++c) p.box.grow_point(&m.vertices[3 * (size_t)m.indices[k + c]]);
+            b.prims.push_back(p);
+        }
+    }
+    for (uint32_t i = 0; i < scene->spheres.size(); ++i) {
+        const ort_sphere &s = scene->spheres[i];
+        Prim p;
+        p.kind = PRIM_SPHERE; p.index = i;
+        float r = fabsf(s.r);
+        p.box.lo[0] = s.center.x - r; p.box.lo[1] = s.center.y - r; p.box.lo[2] = s.center.z - r;
+        p.box.hi[0] = s.center.x + r; p.box.hi[1] = s.center.y + r; p.box.hi[2] = s.center.z + r;
+        b.prims.push_back(p);
+    }
+    for (uint32_t i = 0; i < scene->boxes.size(); ++i) {
+        const ort_box &bx = scene->boxes[i];
+        Prim p;
+        p.kind = PRIM_BOX; p.index = i;
+        p.box.lo[0] = std::min(bx.min.x, bx.max.x); p.box.lo[1] = std::min(bx.min.y, bx.max.y); p.box.lo[2] = std::min(bx.min.z, bx.max.z);
+        p.box.hi[0] = std::max(bx.min.x, bx.max.x); p.box.hi[1] = std::max(bx.min.y, bx.max.y); p.box.hi[2] = std::max(bx.min.z, bx.max.z);
+        b.prims.push_back(p);
+    }
+    for (uint32_t i = 0; i < scene->cylinders.size(); ++i) {
+        const ort_cylinder &c = scene->cylinders[i];
+        Prim p;
+        p.kind = PRIM_CYL; p.index = i;
+        /* bound what the intersector actually tests: the segment base .. base + len * a in the
+           frame of ray.cpp:8-33 (a = +z whenever axis x z ~ 0, even for axis = -z), radius r */
+        float rot[9], len;
+        cylinder_frame(c, rot, &len);
+        const float *a = rot + 6;
+        float p0[3] = {c.base.x, c.base.y, c.base.z};
+        float p1[3] = {p0[0] + len * a[0], p0[1] + len * a[1], p0[2] + len * a[2]};
+        p.box.reset();
+        p.box.grow_point(p0);
+        p.box.grow_point(p1);
+        float r = fabsf(c.r) * 1.0001f;
+        for (int k = 0; k < 3; ++k) {
+            float e = r * sqrtf(std::max(0.0f, 1.0f - a[k] * a[k])) + 1e-5f * r;
+            p.box.lo[k] -= e;
+            p.box.hi[k] += e;
+        }
+        b.prims.push_back(p);
+    }
+    for (Prim &p : b.prims) {
+        pad_box(&p.box);
+        for (int k = 0; k < 3; ++k) {
+            if (!(p.box.lo[k] == p.box.lo[k]) || !(p.box.hi[k] == p.box.hi[k]) || fabsf(p.box.lo[k]) > 1e30f || fabsf(p.box.hi[k]) > 1e30f) {
+                *err = "scene contains a non-finite or oversized primitive";
+                return ORT_ERR_INVALID;
+            }
+            p.centroid[k] = 0.5f * (p.box.lo[k] + p.box.hi[k]);
+        }
+    }
+    if (b.prims.size() > 0x00ffffffu) { *err = "more than 2^24 primitives"; return ORT_ERR_UNSUPPORTED; }
+    tree->tri_slot.assign(b.tri_refs.size(), 0);
+    tree->sphere_slot.assign(scene->spheres.size(), 0);
+    tree->box_slot.assign(scene->boxes.size(), 0);
+    tree->cyl_slot.assign(scene->cylinders.size(), 0);
+
+    /* node 0 always exists and is interior, so traversal starts uniformly */
+    tree->nodes.reserve(b.prims.size() + 2);
+    if (b.prims.empty()) {
+        DevNode n{};
+        for (int k = 0; k < 3; ++k) { n.lo0[k] = n.lo1[k] = FLT_MAX; n.hi0[k] = n.hi1[k] = -FLT_MAX; }
+        n.child0 = n.child1 = EMPTY_CHILD;
+        tree->nodes.push_back(n);
+    } else {
+        Box3 all = b.bounds(0, (uint32_t)b.prims.size());
+        b.root_area = std::max(all.half_area(), 1e-30f);
+        uint32_t root = b.build(0, (uint32_t)b.prims.size(), all, 0);
+        if (root & LEAF_BIT) {
+            DevNode n{};
+            memcpy(n.lo0, all.lo, 12); memcpy(n.hi0, all.hi, 12);
+            for (int k = 0; k < 3; ++k) { n.lo1[k] = FLT_MAX; n.hi1[k] = -FLT_MAX; }
+            n.child0 = root; n.child1 = EMPTY_CHILD;
+            tree->nodes.push_back(n);
+        }
+        tree->sah_cost = (float)(b.sah_sum / b.root_area);
+    }
+    tree->built = true;
+    return ORT_OK;
+}
+
+} // namespace ort

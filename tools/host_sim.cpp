@@ -1,0 +1,119 @@
+/*
+ * tools/host_sim.cpp -- DEVELOPER HARNESS, not part of the product and not a test.
+ *
+ * The dev container has no GPU.  This tool compiles the kernel's lane function
+ * (ort_kernels.hip: pt_lane) as ordinary host C++ (-DORT_HOST_SIM) and runs ONE simulated
+ * lane over the whole job space, so kernel logic can be debugged against the oracle
+ * before spending GPU-box time.  Nothing in offline_raytracer_amd/, tests/, bench.py or
+ * __graft_entry__.py builds, imports or runs it; the product library contains no host
+ * build of the render path.
+ *
+ * build: see tools/Makefile     run: host_sim <scn> <base> W H spp seed policy chunk out.f32
+ */
+#define ORT_HOST_SIM 1
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+static uint32_t *g_pixel_rng; static int g_W;
+static int g_dbg_x = -1, g_dbg_y = -1; static FILE *g_ray_log;
+#define ORT_SIM_RAY_HOOK(PX_, PY_, O_, D_, T_, N_, M_) do { if ((PX_) == g_dbg_x && (PY_) == g_dbg_y && g_ray_log) { float r_[11] = {O_.x, O_.y, O_.z, D_.x, D_.y, D_.z, T_, N_.x, N_.y, N_.z, 0}; unsigned m_ = (M_); fwrite(r_, 4, 10, g_ray_log); fwrite(&m_, 4, 1, g_ray_log); } } while (0)
+#define ORT_SIM_PIXEL_HOOK(x, y, rng) do { if (g_pixel_rng) g_pixel_rng[(y) * g_W + (x)] = (rng); } while (0)
+#include "../offline_raytracer_amd/csrc/ort_kernels.hip"
+
+#include <chrono>
+
+using namespace ort;
+
+int main(int argc, char **argv) {
+    if (argc < 10) { fprintf(stderr, "usage: host_sim scn base W H spp seed policy chunk out.f32 [shard_index shard_count]\n"); return 2; }
+    int W = atoi(argv[3]), H = atoi(argv[4]);
+    uint32_t spp = (uint32_t)strtoul(argv[5], 0, 10), seed = (uint32_t)strtoul(argv[6], 0, 10);
+    std::string policy = argv[7];
+    uint32_t chunk = (uint32_t)strtoul(argv[8], 0, 10);
+    ort_scene *scene = nullptr;
+    if (ort_scene_load_scn(argv[1], argv[2], &scene) != ORT_OK || ort_scene_commit(scene) != ORT_OK) {
+        fprintf(stderr, "scene: %s\n", ort_last_error());
+        return 1;
+    }
+    const Tree &t = scene->tree;
+    ort_tree_info ti;
+    ort_scene_get_tree_info(scene, &ti);
+    fprintf(stderr, "tree: %u nodes, %u leaves, max leaf %u, depth %u, sah %.2f\n", ti.node_count, ti.leaf_count, ti.max_leaf_prims, ti.max_depth, ti.sah_cost);
+
+    std::vector<DevMaterial> mats(scene->materials.size());
+    for (size_t i = 0; i < mats.size(); ++i) {
+        const ort_material &m = scene->materials[i];
+        DevMaterial dm{};
+        dm.diffuse[0] = m.diffuse.x; dm.diffuse[1] = m.diffuse.y; dm.diffuse[2] = m.diffuse.z; dm.ior = m.ior;
+        dm.specular[0] = m.specular[0]; dm.specular[1] = m.specular[1]; dm.specular[2] = m.specular[2];
+        dm.is_light = m.is_light ? 1u : 0u;
+        dm.transmission[0] = m.transmission.x; dm.transmission[1] = m.transmission.y; dm.transmission[2] = m.transmission.z;
+        dm.emit[0] = m.emit.x; dm.emit[1] = m.emit.y; dm.emit[2] = m.emit.z;
+        mats[i] = dm;
+    }
+    std::vector<uint32_t> lis(scene->lights.size());
+    for (size_t i = 0; i < lis.size(); ++i) lis[i] = scene->lights[i].type == 1u;
+
+    SceneView sv{};
+    sv.nodes = (const float4 *)t.nodes.data(); sv.tris = (const float4 *)t.tris.data(); sv.tri_mat = t.tri_mat.data();
+    sv.spheres = (const float4 *)t.spheres.data(); sv.sphere_mat = t.sphere_mat.data();
+    sv.boxes = (const float4 *)t.boxes.data(); sv.box_mat = t.box_mat.data();
+    sv.cyls = (const float4 *)t.cyls.data(); sv.cyl_mat = t.cyl_mat.data();
+    sv.materials = (const float4 *)mats.data();
+    sv.light_is_sphere = lis.data(); sv.light_count = (uint32_t)lis.size();
+    const RefTree &rt = scene->ref;
+    sv.ref_nodes = (const float4 *)rt.nodes.data(); sv.ref_recs = rt.recs.data(); sv.chain_boxes = (const float4 *)rt.chain_boxes.data();
+    sv.tri_chain = rt.tri_chain.data(); sv.sphere_chain = rt.sphere_chain.data(); sv.box_chain = rt.box_chain.data(); sv.cyl_chain = rt.cyl_chain.data();
+    fprintf(stderr, "ref octree: %zu nodes, %u leaves, max leaf %u, chain boxes %zu\n", rt.nodes.size(), rt.nonempty_leaves, rt.max_leaf_records, rt.chain_boxes.size() / 2);
+    ort_camera cam;
+    camera_basis(*scene, W, H, &cam);
+    memcpy(sv.cam, &cam, sizeof(cam));
+
+    std::vector<float> out((size_t)W * H * 3, 0.0f), partial;
+    unsigned long long ctrl[8] = {0};
+    RenderView rv{};
+    rv.W = W; rv.H = H; rv.x0 = 0; rv.y0 = 0; rv.x1 = W; rv.y1 = H;
+    rv.seed = seed; rv.spp = spp; rv.chunk = chunk; rv.rr = 0.8f;
+    rv.out = out.data(); rv.next_job = ctrl; rv.counters = ctrl + 1;
+    rv.shard_count = argc > 11 ? (uint32_t)atoi(argv[11]) : 1; rv.shard_index = argc > 11 ? (uint32_t)atoi(argv[10]) : 0;
+    rv.blocks_w = (uint32_t)((W + 7) / 8);
+    uint32_t blocks_total = rv.blocks_w * (uint32_t)((H + 7) / 8);
+    rv.my_blocks = (blocks_total - rv.shard_index + rv.shard_count - 1) / rv.shard_count;
+    std::vector<ort_tile_job> jobs;
+    std::vector<uint32_t> finals;
+    if (policy == "pixel") { rv.mode = JOBS_PIXEL; rv.nchunks = 1; rv.job_count = (unsigned long long)rv.my_blocks * 64; }
+    else if (policy == "chunk") {
+        rv.mode = JOBS_CHUNK; rv.nchunks = spp / chunk; rv.job_count = (unsigned long long)rv.my_blocks * 64 * rv.nchunks;
+        partial.assign((size_t)rv.nchunks * W * H * 3, 0.0f); rv.partial = partial.data();
+    } else {
+        uint32_t master = seed;
+        auto xs = [&]() { master ^= master << 13; master ^= master >> 17; master ^= master >> 5; return master; };
+        if (policy == "whole") jobs.push_back(ort_tile_job{0, 0, W, H, xs(), spp});
+        else {
+            int tw = (int)ceilf(W / 32.0f), th = (int)ceilf(H / 32.0f);
+            for (int ty = 0; ty < 32; ++ty) for (int tx = 0; tx < 32; ++tx) {
+                ort_tile_job j{tx * tw, ty * th, std::min(W, tx * tw + tw), std::min(H, ty * th + th), xs(), spp};
+                if (j.x0 < j.x1 && j.y0 < j.y1) jobs.push_back(j);
+            }
+        }
+        finals.resize(jobs.size());
+        rv.mode = JOBS_EXPLICIT; rv.jobs = jobs.data(); rv.job_count = jobs.size(); rv.final_states = finals.data();
+    }
+    std::vector<uint32_t> pix_rng((size_t)W * H, 0);
+    if (getenv("SIM_RAY_LOG")) { g_ray_log = fopen(getenv("SIM_RAY_LOG"), "wb"); g_dbg_x = atoi(getenv("SIM_X")); g_dbg_y = atoi(getenv("SIM_Y")); }
+    if (getenv("SIM_DUMP_RNG")) { g_pixel_rng = pix_rng.data(); g_W = W; }
+    std::vector<uint32_t> lds(kLdsStack * kBlock);
+    auto t0 = std::chrono::steady_clock::now();
+    pt_lane<true>(sv, rv, lds.data(), 0);
+    if (rv.mode == JOBS_CHUNK)
+        for (unsigned long long i = 0; i < (unsigned long long)rv.my_blocks * 64; ++i) combine_pixel(rv, i);
+    double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    fprintf(stderr, "sim: %.2fs paths %llu rays %llu node_tests %llu tri_tests %llu analytic %llu fallback %llu%s\n", sec, ctrl[1], ctrl[2], ctrl[3], ctrl[4], ctrl[5], ctrl[6],
+            finals.empty() ? "" : (" final_rng " + std::to_string(finals.back())).c_str());
+    if (g_ray_log) fclose(g_ray_log);
+    if (g_pixel_rng) { FILE *g = fopen(getenv("SIM_DUMP_RNG"), "wb"); fwrite(pix_rng.data(), 4, pix_rng.size(), g); fclose(g); }
+    FILE *f = fopen(argv[9], "wb");
+    fwrite(out.data(), 4, out.size(), f);
+    fclose(f);
+    return 0;
+}
