@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the render call (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one full render of the workload through the C ABI (HIP persistent path-trace
+kernel + chunk combine, output left in HBM) plus, for N > 1, the single RCCL gather of the
+framebuffer to rank 0.  Workload = the configuration the metric is quoted on: the reference's
+bunny.ply (69 451 triangles) in a closed room, 1920x1080, 1024 spp, rr 0.8 -- one frame,
+sharded by 8x8-pixel blocks over the N GPUs (total work fixed => "strong" scaling).
+
+Prints ONE JSON line on rank 0 with the contract fields plus
+  roofline     : algorithmic bytes (SURVEY 8d formula, exact device counters) / kernel time
+  cpu_baseline : the reference's own code (oracle/_ref, kind "reference") or the oracle
+                 (kind "port") timed on this host's cores on a bounded sample; N=1 only.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scene", default="c3_bunny_room")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=1024)
+    ap.add_argument("--chunk", type=int, default=64)
+    ap.add_argument("--seed", type=int, default=12345)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-spp", type=int, default=96)
+    return ap.parse_args()
+
+
+def cpu_baseline(args, scene_path):
+    """The reference's own hot path (compiled from /root/reference by oracle/Makefile; the
+    binary travels, the sources do not) on every host core, on a bounded sample of the same
+    workload: the central 960x540 pixels of the 1920x1080 frame at a reduced spp, per-pixel
+    seeds.  One process per core, each a horizontal band."""
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    W, H = args.width, args.height
+    x0, x1 = W // 4, W - W // 4
+    y0, y1 = H // 4, H - H // 4
+    spp = args.cpu_sample_spp
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "ref_glibc")
+    sample = "central %dx%d px of the %dx%d frame, %d spp, per-pixel seeds" % (x1 - x0, y1 - y0, W, H, spp)
+    if os.path.exists(ref_bin):
+        bands = [(y0 + (y1 - y0) * k // cores, y0 + (y1 - y0) * (k + 1) // cores) for k in range(cores)]
+        procs = []
+        for k, (a, b) in enumerate(bands):
+            if b <= a:
+                continue
+            out = "/tmp/ort_cpu_baseline_%d_%d.f32" % (os.getpid(), k)
+            cmd = [ref_bin, "render", scene_path, os.path.join(ROOT, "data") + "/", str(W), str(H), str(spp),
+                   str(args.seed), "pixel", out, "1", str(x0), str(a), str(x1), str(b)]
+            procs.append((subprocess.Popen(cmd, stdout=subprocess.PIPE), out))
+        paths, slowest = 0.0, 0.0
+        for p, out in procs:
+            text = p.communicate()[0].decode().strip().splitlines()[-1]
+            js = json.loads(text)
+            paths += js["paths"]
+            slowest = max(slowest, js["seconds"])
+            try:
+                os.remove(out)
+            except OSError:
+                pass
+        return {"value": paths / slowest / 1e6, "unit": "Mpaths/s", "cores": len(procs), "kind": "reference",
+                "sample": sample + "; reference ray.cpp built with clang++ -O2 -ffp-contract=off + glibc libm, "
+                "one process per core (horizontal bands), render time only"}
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    from offline_raytracer_amd import api
+    scene = api.Scene.load_scn(scene_path).commit()
+    osc = oracle_lib.OracleScene(scene.flatten(W, H))
+    _, st = osc.render(W, H, spp, args.seed, "pixel", rect=(x0, y0, x1, y1), threads=cores)
+    return {"value": st["paths"] / st["seconds"] / 1e6, "unit": "Mpaths/s", "cores": cores, "kind": "port",
+            "sample": sample + "; oracle/liboracle.so (plain-C restatement), pthreads"}
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    from offline_raytracer_amd import api, dist as odist
+
+    if not torch.cuda.is_available() or api.device_count() < 1:
+        sys.exit("bench.py needs a HIP device: the render path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    scene_path = os.path.join(ROOT, "data", args.scene + ".scn")
+    scene = api.Scene.load_scn(scene_path).commit().upload(local_rank)
+    W, H = args.width, args.height
+    fb = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+    params = api.Scene.params(W, H, args.spp, args.seed, "chunk", chunk=args.chunk, shard=(rank, world))
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(want_stats=False):
+        st = scene.render_device(fb.data_ptr(), params, stream=stream, want_stats=want_stats)
+        if world > 1:
+            odist.gather_framebuffer(fb, W, H, rank, world)
+        return st
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    kernel_ms = []
+    for _ in range(args.steps):
+        st = step(want_stats=True)  # HIP events around the kernel, on the launch stream
+        kernel_ms.append(st["kernel_ms"])
+    fence()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ms_per_step = float(t.item()) / args.steps * 1e3
+    paths_per_step = float(W) * H * args.spp
+    value = paths_per_step / (ms_per_step * 1e-3) / 1e6
+
+    # algorithmic bytes per path from exact device counters (untimed counters build of the same
+    # kernel, same scene/seed/policy at reduced spp: the per-path averages are spp-independent)
+    cparams = api.Scene.params(W, H, args.chunk, args.seed, "chunk", chunk=args.chunk, counters=True, shard=(rank, world))
+    cst = scene.render_device(fb.data_ptr(), cparams, stream=stream, want_stats=True)
+    R = cst["rays"] / max(1, cst["paths"])
+    Vn = cst["node_tests"] / max(1, cst["rays"])
+    Vt = cst["tri_tests"] / max(1, cst["rays"])
+    Vp = cst["analytic_tests"] / max(1, cst["rays"])
+    bytes_per_path = R * (Vn * 32.0 + Vt * 36.0 + Vp * 32.0) + 12.0 / args.spp
+    my_paths = paths_per_step / world  # per launch on this rank (blocks are dealt round-robin)
+    k_ms = sum(kernel_ms) / len(kernel_ms)
+    achieved = bytes_per_path * my_paths / (k_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    if rank == 0:
+        line = {
+            "metric": "Mpaths/s", "value": value, "unit": "Mpaths/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic: build-authored closed-room .scn around the reference's bunny.ply, fixed seed %d" % args.seed,
+            "config": {"workload": "%s.scn (bunny.ply, 69451 triangles) %dx%d %dspp rr0.8, CHUNK policy chunk=%d, "
+                                   "one frame sharded in 8x8 blocks over %d GPU(s)" % (args.scene, W, H, args.spp, args.chunk, world),
+                       "width": W, "height": H, "spp": args.spp, "paths_per_step": paths_per_step},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "pt_persistent", "kernel_ms": k_ms, "bytes_per_path": bytes_per_path,
+                         "rays_per_path": R, "node_tests_per_ray": Vn, "tri_tests_per_ray": Vt,
+                         "analytic_tests_per_ray": Vp, "fallback_rays": cst["fallback_rays"]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args, scene_path)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -221,6 +221,23 @@ int ort_render_image_device(ort_scene *scene, const ort_render_params *params, v
 /* bytes of device workspace ort_render_image_device keeps for these params (CHUNK partial sums) */
 int ort_render_workspace_bytes(const ort_render_params *params, uint64_t *bytes);
 
+/* ---- diagnostics: per-function evaluation ON THE DEVICE (parity tests) -----------------
+ * records: count x {u32 op; f32 in[24]}; out: count x f32[8].  Ops (reference file:line):
+ *  1 triangle  ray.cpp:63-115   in v0 v1 v2 o d              out t n.xyz
+ *  2 sphere    ray.cpp:132-190  in c r o d                   out t n.xyz
+ *  3 aab       ray.cpp:206-283  in min max o d               out t n.xyz
+ *  4 cylinder  ray.cpp:286-352  in base axis r o d           out t n.xyz
+ *  5 sample_brdf ray.cpp:1100   in seed(bits) N wo rough Kd Ks Kt ior   out wi.xyz is_transmission rng(bits)
+ *  6 pdf_brdf  ray.cpp:1007     in N wi wo rough Kd Ks Kt ior           out p
+ *  7 eval_scattering ray.cpp:936 in N wi wo Kd Ks Kt ior rough dist     out f.xyz
+ *  8 sample_lobe ray.cpp:1065   in N c phi                   out v.xyz
+ *  9 libm      (deterministic)  in x y                       out sinf(x) cosf(x) atan2f(y,x) powf(x,y) logf(x)
+ * 10 normalize math.h:298-310   in v                         out v.xyz
+ * 11 fresnel/ggx/geometry ray.cpp:825-897 in Ks l_dot_h N H rough w     out F.xyz D G
+ * 12 rng       random.h:5-53    in seed(bits) job(bits)      out step(bits) rng_01 rng_between(0,2pi) state(bits) job_seed(bits)
+ * 13 IEEE ops                   in a b c                     out a/b sqrt(a) a*b a+b a-b (f32)bits(a) a*b+c */
+int ort_unit_eval_device(int device, const void *records, uint32_t count, float *out);
+
 /* ---- output ------------------------------------------------------------------------
  * v3_to_rgbe (macos_main.mm:242-261) and the .hdr writer (macos_main.mm:263-287,683-707) */
 uint32_t ort_rgbe(float r, float g, float b);

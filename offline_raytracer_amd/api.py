@@ -99,7 +99,7 @@ EXPORTS = [
     "ort_scene_get_boxes", "ort_scene_get_cylinders", "ort_scene_get_lights", "ort_scene_get_mesh",
     "ort_scene_get_camera", "ort_scene_commit", "ort_scene_get_tree_info", "ort_device_count", "ort_scene_upload",
     "ort_tiled_raytrace", "ort_tiled_raytrace_batch", "ort_render_image", "ort_render_image_device",
-    "ort_render_workspace_bytes", "ort_rgbe", "ort_write_hdr"]
+    "ort_render_workspace_bytes", "ort_unit_eval_device", "ort_rgbe", "ort_write_hdr"]
 
 _lib = None
 
@@ -140,6 +140,7 @@ def lib():
         L.ort_render_image_device.argtypes = [C.c_void_p, C.POINTER(RenderParams), C.c_void_p, C.c_void_p,
                                               C.POINTER(Stats)]
         L.ort_render_workspace_bytes.argtypes = [C.POINTER(RenderParams), C.POINTER(C.c_uint64)]
+        L.ort_unit_eval_device.argtypes = [C.c_int, C.c_void_p, C.c_uint32, C.c_void_p]
         L.ort_rgbe.restype = C.c_uint32
         L.ort_rgbe.argtypes = [C.c_float, C.c_float, C.c_float]
         L.ort_write_hdr.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32]
@@ -326,6 +327,15 @@ class Scene:
         _check(lib().ort_tiled_raytrace_batch(self.handle, out.ctypes.data, width, height, jobs.ctypes.data, len(jobs),
                                               rr, finals.ctypes.data, C.byref(st)))
         return finals, st.as_dict()
+
+
+def unit_eval_device(records, device=0):
+    """records: structured array {op: u4, a: f4[24]} -> (n, 8) float32, evaluated by the HIP device functions."""
+    records = np.ascontiguousarray(records)
+    assert records.dtype.itemsize == 100
+    out = np.zeros((len(records), 8), "<f4")
+    _check(lib().ort_unit_eval_device(device, records.ctypes.data, len(records), out.ctypes.data))
+    return out
 
 
 def rgbe(r, g, b):

@@ -317,6 +317,25 @@ int ort_render_image_device(ort_scene *s, const ort_render_params *p, void *d_ou
     return render_common(s, p, d_out_rgb, nullptr, hip_stream, stats);
 }
 
+int ort_unit_eval_device(int device, const void *records, uint32_t count, float *out) {
+    if ((!records || !out) && count) return fail(ORT_ERR_INVALID, "null argument");
+    /* op 4 (cylinder): the kernel consumes the host-precomputed frame; fill it in a copy */
+    std::vector<unsigned char> copy((const unsigned char *)records, (const unsigned char *)records + (size_t)count * 100u);
+    for (uint32_t i = 0; i < count; ++i) {
+        uint32_t op;
+        float a[24];
+        memcpy(&op, &copy[(size_t)i * 100u], 4);
+        if (op != 4u) continue;
+        memcpy(a, &copy[(size_t)i * 100u + 4], 96);
+        ort_cylinder c{{a[0], a[1], a[2]}, {a[3], a[4], a[5]}, a[6], 0};
+        ort::cylinder_frame_for(c, a + 13, a + 22);
+        memcpy(&copy[(size_t)i * 100u + 4], a, 96);
+    }
+    std::string err;
+    int rc = ort::device_unit_eval(device, copy.data(), count, out, &err);
+    return rc == ORT_OK ? ORT_OK : fail(rc, err);
+}
+
 int ort_render_workspace_bytes(const ort_render_params *p, uint64_t *bytes) {
     if (!p || !bytes) return fail(ORT_ERR_INVALID, "null argument");
     *bytes = ort::render_workspace_bytes(p);

@@ -518,6 +518,77 @@ __global__ void __launch_bounds__(kBlock) pt_persistent(SceneView sv, RenderView
     pt_lane<COUNTERS>(sv, rv, lds_stack, (int)threadIdx.x);
 }
 
+/* per-function evaluation on the device, for the parity tests: records of {u32 op; f32 in[24]}
+   -> f32 out[8], op codes as documented in include/ort.h (ort_unit_eval_device) */
+__global__ void unit_eval(const uint32_t *records, uint32_t n, float *out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t *rec = records + 25u * i;
+    uint32_t op = rec[0];
+    float a[24];
+    for (int k = 0; k < 24; ++k) a[k] = om_bits_f32(rec[1 + k]);
+    float o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto in3 = [&](int k) { return mk(a[k], a[k + 1], a[k + 2]); };
+    V3 n3 = mk(0, 0, 0);
+    switch (op) {
+    case 1: {
+        V3 v0 = in3(0), e1 = sub(in3(3), v0), e2 = sub(in3(6), v0);
+        float t = hit_triangle(v0, e1, e2, in3(9), in3(12));
+        o[0] = t;
+        if (t >= 0.0f) { V3 c = cross(e1, e2); o[1] = c.x; o[2] = c.y; o[3] = c.z; }
+    } break;
+    case 2: { float t = hit_sphere(in3(0), a[3], in3(4), in3(7), n3); o[0] = t; o[1] = n3.x; o[2] = n3.y; o[3] = n3.z; } break;
+    case 3: { float t = hit_aab(in3(0), in3(3), in3(6), in3(9), n3); o[0] = t; o[1] = n3.x; o[2] = n3.y; o[3] = n3.z; } break;
+    case 4: {
+        /* host-precomputed frame arrives in a[13..22]: rot rows (9) + |axis| */
+        float t = hit_cylinder(in3(0), a[6], in3(13), in3(16), in3(19), a[22], in3(7), in3(10), n3);
+        o[0] = t; o[1] = n3.x; o[2] = n3.y; o[3] = n3.z;
+    } break;
+    case 5: {
+        uint32_t seed = om_f32_bits(a[0]);
+        Mat m; m.kd = in3(8); m.ks = in3(11); m.kt = in3(14); m.ior = a[17]; m.is_light = 0; m.emit = mk(0, 0, 0);
+        bool tr;
+        V3 wi = sample_brdf(seed, in3(1), in3(4), a[7], m, tr);
+        o[0] = wi.x; o[1] = wi.y; o[2] = wi.z; o[3] = tr ? 1.0f : 0.0f; o[4] = om_bits_f32(seed);
+    } break;
+    case 6: {
+        Mat m; m.kd = in3(10); m.ks = in3(13); m.kt = in3(16); m.ior = a[19]; m.is_light = 0; m.emit = mk(0, 0, 0);
+        o[0] = pdf_brdf(in3(0), in3(3), in3(6), a[9], m);
+    } break;
+    case 7: {
+        Mat m; m.kd = in3(9); m.ks = in3(12); m.kt = in3(15); m.ior = a[18]; m.is_light = 0; m.emit = mk(0, 0, 0);
+        V3 f = eval_scattering(in3(0), in3(3), in3(6), m, a[19], a[20]);
+        o[0] = f.x; o[1] = f.y; o[2] = f.z;
+    } break;
+    case 8: { V3 r = sample_lobe(in3(0), a[3], a[4]); o[0] = r.x; o[1] = r.y; o[2] = r.z; } break;
+    case 9:
+        o[0] = ort_sinf(a[0]); o[1] = ort_cosf(a[0]); o[2] = ort_atan2f(a[1], a[0]); o[3] = ort_powf(a[0], a[1]); o[4] = ort_logf(a[0]);
+        break;
+    case 10: { V3 r = normalize(in3(0)); o[0] = r.x; o[1] = r.y; o[2] = r.z; } break;
+    case 11: {
+        V3 F = fresnel(in3(0), a[3]);
+        o[0] = F.x; o[1] = F.y; o[2] = F.z;
+        o[3] = ggx_d(in3(4), in3(7), a[10]);
+        o[4] = geom(in3(11), in3(4), in3(7), a[10]);
+    } break;
+    case 12: { /* RNG: seed -> state after one step, rng_01, rng_between(0, 2pi) from the same seed */
+        uint32_t s0 = om_f32_bits(a[0]), s1 = s0, s2 = s0;
+        rng_step(s0);
+        o[0] = om_bits_f32(s0);
+        o[1] = rng_01(s1);
+        o[2] = rng_between(s2, 0.0f, 2 * kPi);
+        o[3] = om_bits_f32(s2);
+        o[4] = om_bits_f32(job_seed(om_f32_bits(a[0]), om_f32_bits(a[1])));
+    } break;
+    case 13: { /* raw IEEE f32 arithmetic: the bit-exactness premise (div, sqrt, mul, add, sub, u32->f32) */
+        o[0] = a[0] / a[1]; o[1] = __builtin_sqrtf(a[0]); o[2] = a[0] * a[1]; o[3] = a[0] + a[1]; o[4] = a[0] - a[1];
+        o[5] = (float)om_f32_bits(a[0]); o[6] = a[0] * a[1] + a[2];
+    } break;
+    default: break;
+    }
+    for (int k = 0; k < 8; ++k) out[8u * i + k] = o[k];
+}
+
 __global__ void combine_chunks(RenderView rv) {
     unsigned long long idx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (unsigned long long)rv.my_blocks * 64ull) return;
@@ -617,6 +688,24 @@ int device_upload(Scene *scene, int device, std::string *err) {
     hipDeviceProp_t prop;
     ORT_HIP(hipGetDeviceProperties(&prop, device));
     d->cu_count = prop.multiProcessorCount;
+    return ORT_OK;
+}
+
+int device_unit_eval(int device, const void *records, uint32_t n, float *out, std::string *err) {
+    int count = 0;
+    int rc = device_count(&count, err);
+    if (rc != ORT_OK) return rc;
+    if (device < 0 || device >= count) { *err = "no such HIP device"; return ORT_ERR_NO_DEVICE; }
+    ORT_HIP(hipSetDevice(device));
+    void *d_rec = nullptr, *d_out = nullptr;
+    ORT_HIP(hipMalloc(&d_rec, (size_t)n * 100u + 16));
+    ORT_HIP(hipMalloc(&d_out, (size_t)n * 32u + 16));
+    ORT_HIP(hipMemcpy(d_rec, records, (size_t)n * 100u, hipMemcpyHostToDevice));
+    if (n) hipLaunchKernelGGL(unit_eval, dim3((n + 63) / 64), dim3(64), 0, 0, (const uint32_t *)d_rec, n, (float *)d_out);
+    ORT_HIP(hipGetLastError());
+    ORT_HIP(hipMemcpy(out, d_out, (size_t)n * 32u, hipMemcpyDeviceToHost));
+    ORT_HIP(hipFree(d_rec));
+    ORT_HIP(hipFree(d_out));
     return ORT_OK;
 }
 

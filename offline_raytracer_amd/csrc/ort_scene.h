@@ -149,6 +149,9 @@ void device_release(Scene *scene);
 int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *jobs, uint32_t job_count,
                   void *d_out, float *h_out, void *stream, uint32_t *final_states, ort_stats *stats, std::string *err);
 uint64_t render_workspace_bytes(const ort_render_params *p);
+int device_unit_eval(int device, const void *records, uint32_t n, float *out, std::string *err);
+/* ort_tree.cpp: rotation_matrix_along_z(axis) rows + |axis| as the kernel receives them */
+void cylinder_frame_for(const ort_cylinder &c, float rot[9], float *len);
 
 } // namespace ort
 

@@ -293,6 +293,8 @@ struct Builder {
 
 } // namespace
 
+void cylinder_frame_for(const ort_cylinder &c, float rot[9], float *len) { cylinder_frame(c, rot, len); }
+
 int build_tree(Scene *scene, std::string *err) {
     Tree fresh;
     scene->tree = fresh;
