@@ -54,6 +54,8 @@ def cpu_baseline(args, scene_path):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    # a 1-GPU box's CPU share is 16 cores (each reference process also reserves ~0.5 GB of arenas)
+    cores = max(1, min(cores, int(os.environ.get("ORT_CPU_BASELINE_CORES", "16"))))
     W, H = args.width, args.height
     x0, x1 = W // 4, W - W // 4
     y0, y1 = H // 4, H - H // 4

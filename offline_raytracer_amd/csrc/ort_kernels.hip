@@ -50,6 +50,7 @@ struct SceneView {
     const uint32_t *ref_recs;
     const float4 *chain_boxes; /* 2 per chain entry */
     const uint32_t *tri_chain, *sphere_chain, *box_chain, *cyl_chain;
+    const uint32_t *tri_order, *sphere_order, *box_order, *cyl_order; /* reference test order (ties) */
 };
 
 enum : int { JOBS_EXPLICIT = 0, JOBS_PIXEL = 1, JOBS_CHUNK = 2 };
@@ -77,6 +78,7 @@ struct DeviceScene {
     uint32_t light_count = 0;
     void *ref_nodes = nullptr, *ref_recs = nullptr, *chain_boxes = nullptr;
     void *tri_chain = nullptr, *sphere_chain = nullptr, *box_chain = nullptr, *cyl_chain = nullptr;
+    void *tri_order = nullptr, *sphere_order = nullptr, *box_order = nullptr, *cyl_order = nullptr;
     unsigned long long *ctrl = nullptr; /* [0] next_job, [1..5] counters */
     float *partial = nullptr;
     size_t partial_bytes = 0;
@@ -116,6 +118,11 @@ enum : int { PS_NEED_JOB = 0, PS_PIXEL = 1, PS_SAMPLE = 2, PS_HIT = 3, PS_DONE =
 
 constexpr uint32_t kNoPrim = 0xffffffffu;
 
+ORT_D uint32_t prim_order(const SceneView &sv, uint32_t kind, uint32_t slot) {
+    return (kind == PRIM_TRI) ? sv.tri_order[slot] : (kind == PRIM_SPHERE) ? sv.sphere_order[slot]
+         : (kind == PRIM_BOX) ? sv.box_order[slot] : sv.cyl_order[slot];
+}
+
 /* one primitive against the ray, exactly as raycast_bvh does per record (ray.cpp:647-716):
    accept when hit_t >= 1e-6 and strictly closer than the best so far */
 template <bool COUNTERS>
@@ -143,7 +150,13 @@ ORT_D void test_prim(const SceneView &sv, uint32_t kind, uint32_t slot, V3 org, 
         if (COUNTERS) c_analytic++;
         t = hit_cylinder(mk(a.x, a.y, a.z), a.w, mk(b.x, b.y, b.z), mk(b.w, c.x, c.y), mk(c.z, c.w, d.x), d.y, org, dir, n);
     }
-    if (t >= kHitTMin && t < best_t) {
+    bool take = (t >= kHitTMin && t < best_t);
+    if (t == best_t && t >= kHitTMin && hit_prim != kNoPrim) {
+        /* bit-equal distance (e.g. the shared diagonal of a fan-triangulated quad): the reference
+           keeps whichever it tested first */
+        take = prim_order(sv, kind, slot) < prim_order(sv, hit_prim >> 28, hit_prim & 0x00ffffffu);
+    }
+    if (take) {
         best_t = t;
         hit_n = n;
         hit_prim = (kind << 28) | slot;
@@ -627,7 +640,7 @@ void device_release(Scene *scene) {
     (void)hipSetDevice(d->device);
     void *ptrs[] = {d->nodes, d->tris, d->tri_mat, d->spheres, d->sphere_mat, d->boxes, d->box_mat, d->cyls, d->cyl_mat,
                     d->materials, d->light_is_sphere, d->ref_nodes, d->ref_recs, d->chain_boxes, d->tri_chain, d->sphere_chain,
-                    d->box_chain, d->cyl_chain, d->ctrl, d->partial, d->staging, d->jobs, d->states};
+                    d->box_chain, d->cyl_chain, d->tri_order, d->sphere_order, d->box_order, d->cyl_order, d->ctrl, d->partial, d->staging, d->jobs, d->states};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (d->ev0) (void)hipEventDestroy(d->ev0);
@@ -681,6 +694,10 @@ int device_upload(Scene *scene, int device, std::string *err) {
     if ((rc = upload_vec(rt.sphere_chain, &d->sphere_chain, err))) return rc;
     if ((rc = upload_vec(rt.box_chain, &d->box_chain, err))) return rc;
     if ((rc = upload_vec(rt.cyl_chain, &d->cyl_chain, err))) return rc;
+    if ((rc = upload_vec(rt.tri_order, &d->tri_order, err))) return rc;
+    if ((rc = upload_vec(rt.sphere_order, &d->sphere_order, err))) return rc;
+    if ((rc = upload_vec(rt.box_order, &d->box_order, err))) return rc;
+    if ((rc = upload_vec(rt.cyl_order, &d->cyl_order, err))) return rc;
     ORT_HIP(hipMalloc((void **)&d->ctrl, 8 * sizeof(unsigned long long)));
     ORT_HIP(hipMemset(d->ctrl, 0, 8 * sizeof(unsigned long long)));
     ORT_HIP(hipEventCreate(&d->ev0));
@@ -753,6 +770,8 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
     sv.chain_boxes = (const float4 *)d->chain_boxes;
     sv.tri_chain = (const uint32_t *)d->tri_chain; sv.sphere_chain = (const uint32_t *)d->sphere_chain;
     sv.box_chain = (const uint32_t *)d->box_chain; sv.cyl_chain = (const uint32_t *)d->cyl_chain;
+    sv.tri_order = (const uint32_t *)d->tri_order; sv.sphere_order = (const uint32_t *)d->sphere_order;
+    sv.box_order = (const uint32_t *)d->box_order; sv.cyl_order = (const uint32_t *)d->cyl_order;
     ort_camera cam;
     camera_basis(*scene, p->width, p->height, &cam);
     memcpy(sv.cam, &cam, sizeof(cam));

@@ -252,6 +252,30 @@ int build_ref_tree(Scene *scene, std::string *err) {
             }
         }
     }
+    /* static breadth-first numbering of every record = the order in which the reference tests
+       shapes along any ray (unvisited nodes only drop out of the sequence) */
+    out->tri_order.assign(tree.tris.size(), 0);
+    out->sphere_order.assign(tree.spheres.size(), 0);
+    out->box_order.assign(tree.boxes.size(), 0);
+    out->cyl_order.assign(tree.cyls.size(), 0);
+    {
+        std::vector<uint32_t> queue;
+        queue.push_back(0);
+        uint32_t next = 0;
+        for (size_t head = 0; head < queue.size(); ++head) {
+            const DevRefNode &d = out->nodes[queue[head]];
+            for (uint32_t r = 0; r < d.rec_count; ++r) {
+                uint32_t rec = out->recs[d.rec_first + r], kind = rec >> 28, slot = rec & 0x00ffffffu;
+                if (kind == PRIM_TRI) out->tri_order[slot] = next;
+                else if (kind == PRIM_SPHERE) out->sphere_order[slot] = next;
+                else if (kind == PRIM_BOX) out->box_order[slot] = next;
+                else out->cyl_order[slot] = next;
+                ++next;
+            }
+            if (d.first_child >= 0)
+                for (uint32_t k = 0; k < 8; ++k) queue.push_back((uint32_t)d.first_child + k);
+        }
+    }
     out->built = true;
     return ORT_OK;
 }

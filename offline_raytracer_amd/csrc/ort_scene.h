@@ -101,6 +101,10 @@ struct RefTree {
     std::vector<uint32_t> recs;
     std::vector<F4> chain_boxes;
     std::vector<uint32_t> tri_chain, sphere_chain, box_chain, cyl_chain;
+    /* position of each primitive in the reference's test order: raycast_bvh walks breadth-first
+       (children in slot order) and a node's records in push order, and among bit-equal hit
+       distances the first one tested wins (strict <, ray.cpp:653,670,686,708) */
+    std::vector<uint32_t> tri_order, sphere_order, box_order, cyl_order;
     uint32_t nonempty_leaves = 0, max_leaf_records = 0;
     bool built = false;
 };

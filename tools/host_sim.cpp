@@ -64,6 +64,7 @@ int main(int argc, char **argv) {
     const RefTree &rt = scene->ref;
     sv.ref_nodes = (const float4 *)rt.nodes.data(); sv.ref_recs = rt.recs.data(); sv.chain_boxes = (const float4 *)rt.chain_boxes.data();
     sv.tri_chain = rt.tri_chain.data(); sv.sphere_chain = rt.sphere_chain.data(); sv.box_chain = rt.box_chain.data(); sv.cyl_chain = rt.cyl_chain.data();
+    sv.tri_order = rt.tri_order.data(); sv.sphere_order = rt.sphere_order.data(); sv.box_order = rt.box_order.data(); sv.cyl_order = rt.cyl_order.data();
     fprintf(stderr, "ref octree: %zu nodes, %u leaves, max leaf %u, chain boxes %zu\n", rt.nodes.size(), rt.nonempty_leaves, rt.max_leaf_records, rt.chain_boxes.size() / 2);
     ort_camera cam;
     camera_basis(*scene, W, H, &cam);
