@@ -12,7 +12,7 @@ import subprocess
 import numpy as np
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "lib", "libort.so")
+LIB_PATH = os.environ.get("ORT_LIB", os.path.join(PKG_DIR, "lib", "libort.so"))  # ORT_LIB: tuning builds only
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 
 OK, ERR_INVALID, ERR_IO, ERR_PARSE, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_STATE = range(8)

@@ -253,8 +253,11 @@ ORT_D float hit_triangle(V3 v0, V3 e1, V3 e2, V3 o, V3 d) {
     return t;
 }
 
-ORT_D float hit_sphere(V3 c, float rad, V3 o, V3 d, V3 &n) {                      /* ray.cpp:132-190 */
+/* tangent = the hit came from the "one intersection point" branch, whose t = -b/(2a) is half the
+   distance to the closest approach (sic): a point outside the sphere */
+ORT_D float hit_sphere(V3 c, float rad, V3 o, V3 d, V3 &n, bool &tangent) {       /* ray.cpp:132-190 */
     float ht = -1.0f;
+    tangent = false;
     V3 rel = sub(o, c);
     float a = dot(d, d), b = dot(d, rel), cc = dot(rel, rel) - rad * rad;
     float root = b * b - a * cc;
@@ -272,14 +275,16 @@ ORT_D float hit_sphere(V3 c, float rad, V3 o, V3 d, V3 &n) {                    
         if (t > kHitTMin) {
             ht = t;
             n = sub(add(o, scale(ht, d)), c);
+            tangent = true;
         }
     }
     return ht;
 }
 
-ORT_D float hit_aab(V3 lo, V3 hi, V3 o, V3 d, V3 &n) {                            /* ray.cpp:206-283 */
+/* ray.cpp:206-283; inv = (1/d.x, 1/d.y, 1/d.z) is the reference's own per-call value (ray.cpp:210),
+   computed once per ray by the caller */
+ORT_D float hit_aab(V3 lo, V3 hi, V3 o, V3 inv, V3 &n) {
     float ht = -1.0f;
-    V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     V3 t0 = had(sub(lo, o), inv), t1 = had(sub(hi, o), inv);
     V3 tmin = mk(rmin(t0.x, t1.x), rmin(t0.y, t1.y), rmin(t0.z, t1.z));
     V3 tmax = mk(rmax(t0.x, t1.x), rmax(t0.y, t1.y), rmax(t0.z, t1.z));
@@ -299,6 +304,14 @@ ORT_D float hit_aab(V3 lo, V3 hi, V3 o, V3 d, V3 &n) {                          
         n = bn;
     }
     return ht;
+}
+
+/* the same, distance only (node admission tests of the reference octree) */
+ORT_D float hit_aab_t(V3 lo, V3 hi, V3 o, V3 inv) {
+    V3 t0 = had(sub(lo, o), inv), t1 = had(sub(hi, o), inv);
+    float max_of_min = rmax(rmax(rmin(t0.x, t1.x), rmin(t0.y, t1.y)), rmin(t0.z, t1.z));
+    float min_of_max = rmin(rmin(rmax(t0.x, t1.x), rmax(t0.y, t1.y)), rmax(t0.z, t1.z));
+    return (min_of_max >= max_of_min) ? max_of_min : -1.0f;
 }
 
 /* ray.cpp:286-352 with rotation_matrix_along_z(axis) (ray.cpp:8-33) and |axis| precomputed */

@@ -14,7 +14,9 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -29,7 +31,8 @@ using namespace ortd;
 
 constexpr int kBlock = 256;      /* 4 waves */
 constexpr int kLdsStack = 24;    /* entries per lane in LDS: 24 * 256 * 4 B = 24 KB per block */
-constexpr int kSpillStack = 64;  /* scratch tail; ort_tree.cpp bounds the depth at 60; the octree fallback needs 7*10+8 */
+constexpr int kSpillStack = 40;  /* scratch tail; ort_tree.cpp bounds the depth at 60 */
+constexpr uint32_t kBfsQueue = 2048; /* live entries of the breadth-first fallback, per lane, in HBM */
 
 struct SceneView {
     const float4 *nodes;      /* 4 per node */
@@ -51,6 +54,7 @@ struct SceneView {
     const float4 *chain_boxes; /* 2 per chain entry */
     const uint32_t *tri_chain, *sphere_chain, *box_chain, *cyl_chain;
     const uint32_t *tri_order, *sphere_order, *box_order, *cyl_order; /* reference test order (ties) */
+    uint32_t *bfs_queue;       /* kBfsQueue entries per lane: ring buffer of the exact fallback */
 };
 
 enum : int { JOBS_EXPLICIT = 0, JOBS_PIXEL = 1, JOBS_CHUNK = 2 };
@@ -63,6 +67,7 @@ struct RenderView {
     int W, H, x0, y0, x1, y1;
     uint32_t seed, spp, chunk, nchunks;
     float rr;
+    int refill_below; /* leave the traversal loop when fewer lanes than this are still tracing */
     uint32_t shard_index, shard_count, blocks_w, my_blocks;
     float *out;      /* W*H*3 */
     float *partial;  /* nchunks * W*H*3 (CHUNK) */
@@ -79,6 +84,8 @@ struct DeviceScene {
     void *ref_nodes = nullptr, *ref_recs = nullptr, *chain_boxes = nullptr;
     void *tri_chain = nullptr, *sphere_chain = nullptr, *box_chain = nullptr, *cyl_chain = nullptr;
     void *tri_order = nullptr, *sphere_order = nullptr, *box_order = nullptr, *cyl_order = nullptr;
+    void *bfs_queue = nullptr;
+    unsigned int max_blocks = 0;
     unsigned long long *ctrl = nullptr; /* [0] next_job, [1..5] counters */
     float *partial = nullptr;
     size_t partial_bytes = 0;
@@ -116,7 +123,11 @@ enum : int { PS_NEED_JOB = 0, PS_PIXEL = 1, PS_SAMPLE = 2, PS_HIT = 3, PS_DONE =
 #endif
 
 
+#ifndef ORT_TRAV_WHILEWHILE
+#define ORT_TRAV_WHILEWHILE 1
+#endif
 constexpr uint32_t kNoPrim = 0xffffffffu;
+constexpr uint32_t kTraversalDone = 0xffffffffu; /* == EMPTY_CHILD: a leaf word no tree contains */
 
 ORT_D uint32_t prim_order(const SceneView &sv, uint32_t kind, uint32_t slot) {
     return (kind == PRIM_TRI) ? sv.tri_order[slot] : (kind == PRIM_SPHERE) ? sv.sphere_order[slot]
@@ -125,11 +136,12 @@ ORT_D uint32_t prim_order(const SceneView &sv, uint32_t kind, uint32_t slot) {
 
 /* one primitive against the ray, exactly as raycast_bvh does per record (ray.cpp:647-716):
    accept when hit_t >= 1e-6 and strictly closer than the best so far */
-template <bool COUNTERS>
-ORT_D void test_prim(const SceneView &sv, uint32_t kind, uint32_t slot, V3 org, V3 dir, float &best_t, V3 &hit_n,
-                     uint32_t &hit_prim, unsigned long long &c_tris, unsigned long long &c_analytic) {
+template <bool COUNTERS, bool EXACT_ORDER>
+ORT_D void test_prim(const SceneView &sv, uint32_t kind, uint32_t slot, V3 org, V3 dir, V3 inv_d, float &best_t, V3 &hit_n,
+                     uint32_t &hit_prim, float &phantom_t, unsigned long long &c_tris, unsigned long long &c_analytic) {
     float t;
     V3 n = mk(0, 0, 0);
+    bool tangent = false;
     if (kind == PRIM_TRI) {
         const float4 *tp = sv.tris + 3u * slot;
         float4 a = tp[0], b = tp[1], c = tp[2];
@@ -139,19 +151,25 @@ ORT_D void test_prim(const SceneView &sv, uint32_t kind, uint32_t slot, V3 org, 
     } else if (kind == PRIM_SPHERE) {
         float4 s = sv.spheres[slot];
         if (COUNTERS) c_analytic++;
-        t = hit_sphere(mk(s.x, s.y, s.z), s.w, org, dir, n);
+        t = hit_sphere(mk(s.x, s.y, s.z), s.w, org, dir, n, tangent);
     } else if (kind == PRIM_BOX) {
         float4 lo = sv.boxes[2u * slot], hi = sv.boxes[2u * slot + 1u];
         if (COUNTERS) c_analytic++;
-        t = hit_aab(mk(lo.x, lo.y, lo.z), mk(hi.x, hi.y, hi.z), org, dir, n);
+        t = hit_aab(mk(lo.x, lo.y, lo.z), mk(hi.x, hi.y, hi.z), org, inv_d, n);
     } else {
         const float4 *cp = sv.cyls + 4u * slot;
         float4 a = cp[0], b = cp[1], c = cp[2], d = cp[3];
         if (COUNTERS) c_analytic++;
         t = hit_cylinder(mk(a.x, a.y, a.z), a.w, mk(b.x, b.y, b.z), mk(b.w, c.x, c.y), mk(c.z, c.w, d.x), d.y, org, dir, n);
     }
+    if (!EXACT_ORDER && tangent) {
+        /* a phantom hit outside its box: whether the reference sees it depends on its visiting
+           order, so it never competes here; the caller re-casts the ray exactly if it could win */
+        phantom_t = fminf(phantom_t, t);
+        return;
+    }
     bool take = (t >= kHitTMin && t < best_t);
-    if (t == best_t && t >= kHitTMin && hit_prim != kNoPrim) {
+    if (!EXACT_ORDER && t == best_t && t >= kHitTMin && hit_prim != kNoPrim) {
         /* bit-equal distance (e.g. the shared diagonal of a fan-triangulated quad): the reference
            keeps whichever it tested first */
         take = prim_order(sv, kind, slot) < prim_order(sv, hit_prim >> 28, hit_prim & 0x00ffffffu);
@@ -165,14 +183,13 @@ ORT_D void test_prim(const SceneView &sv, uint32_t kind, uint32_t slot, V3 org, 
 
 /* the reference's child test without its "closer than best" clause (ray.cpp:788-803):
    origin inside the box (half-open), or the slab test enters at t >= 1e-6 */
-ORT_D bool ref_node_admits(V3 lo, V3 hi, V3 org, V3 dir) {
+ORT_D bool ref_node_admits(V3 lo, V3 hi, V3 org, V3 inv_d) {
     if ((org.x >= lo.x && org.x < hi.x) && (org.y >= lo.y && org.y < hi.y) && (org.z >= lo.z && org.z < hi.z)) return true;
-    V3 n;
-    return hit_aab(lo, hi, org, dir, n) >= kHitTMin;
+    return hit_aab_t(lo, hi, org, inv_d) >= kHitTMin;
 }
 
 /* would the reference have reached this primitive?  Every node box on the way down must admit the ray. */
-ORT_D bool chain_admits(const SceneView &sv, uint32_t prim, V3 org, V3 dir) {
+ORT_D bool chain_admits(const SceneView &sv, uint32_t prim, V3 org, V3 inv_d) {
     uint32_t kind = prim >> 28, slot = prim & 0x00ffffffu;
     uint32_t word = (kind == PRIM_TRI) ? sv.tri_chain[slot]
                   : (kind == PRIM_SPHERE) ? sv.sphere_chain[slot]
@@ -180,31 +197,36 @@ ORT_D bool chain_admits(const SceneView &sv, uint32_t prim, V3 org, V3 dir) {
     uint32_t len = word >> 28, first = word & 0x0fffffffu;
     for (uint32_t i = 0; i < len; ++i) {
         float4 lo = sv.chain_boxes[2u * (first + i)], hi = sv.chain_boxes[2u * (first + i) + 1u];
-        if (!ref_node_admits(mk(lo.x, lo.y, lo.z), mk(hi.x, hi.y, hi.z), org, dir)) return false;
+        if (!ref_node_admits(mk(lo.x, lo.y, lo.z), mk(hi.x, hi.y, hi.z), org, inv_d)) return false;
     }
     return true;
 }
 
-/* exact fallback: raycast_bvh (ray.cpp:624-822) on the reference-compatible octree, depth-first.
-   Same admission rule and same per-record acceptance as the reference; only the visiting order
-   differs (it matters only for bit-equal-t ties). */
+/* exact fallback: raycast_bvh (ray.cpp:624-822) emulated literally on the reference-compatible
+   octree -- breadth-first, children in slot order, records in push order, a child admitted when
+   the origin is inside it or 1e-6 <= t_entry < best AT THAT MOMENT.  The reference never reuses
+   queue memory within a ray; the emulation keeps only the live entries in a ring in HBM.
+   Returns false if the ring overflowed (the render call then fails). */
 template <bool COUNTERS>
-ORT_D void ref_raycast(const SceneView &sv, V3 org, V3 dir, uint32_t *lds_stack, uint32_t *spill, int tid, float &best_t,
-                       V3 &hit_n, uint32_t &hit_prim, unsigned long long &c_nodes, unsigned long long &c_tris,
-                       unsigned long long &c_analytic) {
+ORT_D bool ref_raycast_bfs(const SceneView &sv, V3 org, V3 dir, V3 inv_d, uint32_t *queue, float &best_t, V3 &hit_n,
+                           uint32_t &hit_prim, unsigned long long &c_nodes, unsigned long long &c_tris,
+                           unsigned long long &c_analytic) {
     best_t = 3.402823466e+38f;
     hit_n = mk(0, 0, 0);
     hit_prim = kNoPrim;
-    int sp = 0;
-    uint32_t node = 0;
-    for (;;) {
+    float unused = 0;
+    uint32_t head = 0, tail = 0;
+    bool ok = true;
+    queue[tail++ & (kBfsQueue - 1u)] = 0;
+    while (head != tail) {
+        uint32_t node = queue[head++ & (kBfsQueue - 1u)];
         const float4 *np = sv.ref_nodes + 3u * node;
         float4 a = np[0], b = np[1], c = np[2];
         int32_t first_child = (int32_t)om_f32_bits(a.w);
         uint32_t rec_first = om_f32_bits(b.w), rec_count = om_f32_bits(c.x);
         for (uint32_t r = 0; r < rec_count; ++r) {
             uint32_t rec = sv.ref_recs[rec_first + r];
-            test_prim<COUNTERS>(sv, rec >> 28, rec & 0x00ffffffu, org, dir, best_t, hit_n, hit_prim, c_tris, c_analytic);
+            test_prim<COUNTERS, true>(sv, rec >> 28, rec & 0x00ffffffu, org, dir, inv_d, best_t, hit_n, hit_prim, unused, c_tris, c_analytic);
         }
         if (first_child >= 0) {
             for (uint32_t k = 0; k < 8u; ++k) {
@@ -218,26 +240,22 @@ ORT_D void ref_raycast(const SceneView &sv, V3 org, V3 dir, uint32_t *lds_stack,
                 V3 lo = mk(ca.x, ca.y, ca.z), hi = mk(cb.x, cb.y, cb.z);
                 bool add = (org.x >= lo.x && org.x < hi.x) && (org.y >= lo.y && org.y < hi.y) && (org.z >= lo.z && org.z < hi.z);
                 if (!add) {
-                    V3 n;
-                    float t = hit_aab(lo, hi, org, dir, n);
+                    float t = hit_aab_t(lo, hi, org, inv_d);
                     if (COUNTERS) c_nodes++;
                     add = (t >= kHitTMin && t < best_t);
                 }
                 if (add) {
-                    if (sp < kLdsStack) lds_stack[sp * kBlock + tid] = ci;
-                    else if (sp - kLdsStack < kSpillStack) spill[sp - kLdsStack] = ci;
-                    sp++;
+                    if (tail - head >= kBfsQueue) { ok = false; continue; }
+                    queue[tail++ & (kBfsQueue - 1u)] = ci;
                 }
             }
         }
-        if (sp == 0) break;
-        sp--;
-        node = (sp < kLdsStack) ? lds_stack[sp * kBlock + tid] : spill[sp - kLdsStack];
     }
+    return ok;
 }
 
 template <bool COUNTERS>
-ORT_D void pt_lane(const SceneView &sv, const RenderView &rv, uint32_t *lds_stack, const int tid) {
+ORT_D void pt_lane(const SceneView &sv, const RenderView &rv, uint32_t *lds_stack, const int tid, const uint32_t lane_id) {
     uint32_t spill[kSpillStack];
 
     const V3 cam_p = mk(sv.cam[0], sv.cam[1], sv.cam[2]);
@@ -266,6 +284,8 @@ ORT_D void pt_lane(const SceneView &sv, const RenderView &rv, uint32_t *lds_stac
     float best_t = 0;
     V3 hit_n = mk(0, 0, 0), inv_d = mk(0, 0, 0);
     uint32_t hit_prim = kNoPrim;
+    float phantom_t = 0;
+    bool overflow = false;
 
     unsigned long long c_paths = 0, c_rays = 0, c_nodes = 0, c_tris = 0, c_analytic = 0, c_fallback = 0;
 
@@ -326,9 +346,11 @@ ORT_D void pt_lane(const SceneView &sv, const RenderView &rv, uint32_t *lds_stac
                     /* a traversal has finished: ray.cpp:817 then :1251-1277 (primary) or :1355-1421 (bounce) */
                     bool alive = true;
                     /* the reference only sees a shape through the node boxes above it (ray.cpp:788-803) */
-                    if (hit_prim != kNoPrim && !chain_admits(sv, hit_prim, org, dir)) {
-                        if (COUNTERS) c_fallback++;
-                        ref_raycast<COUNTERS>(sv, org, dir, lds_stack, spill, tid, best_t, hit_n, hit_prim, c_nodes, c_tris, c_analytic);
+                    if ((hit_prim != kNoPrim && !chain_admits(sv, hit_prim, org, inv_d)) || phantom_t <= best_t) {
+                        c_fallback++;
+                        if (!ref_raycast_bfs<COUNTERS>(sv, org, dir, inv_d, sv.bfs_queue + (size_t)lane_id * kBfsQueue, best_t, hit_n,
+                                                       hit_prim, c_nodes, c_tris, c_analytic))
+                            overflow = true;
                     }
                     uint32_t hit_mat = 0;
                     if (hit_prim != kNoPrim) {
@@ -436,20 +458,30 @@ ORT_D void pt_lane(const SceneView &sv, const RenderView &rv, uint32_t *lds_stac
                 best_t = 3.402823466e+38f; /* Flt_Max, ray.cpp:627 */
                 hit_n = mk(0, 0, 0);
                 hit_prim = kNoPrim;
-                inv_d = mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+                phantom_t = __builtin_inff(); /* none yet; compared with <= against best_t (<= FLT_MAX) */
+                inv_d = mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z); /* ray.cpp:210, once per ray */
                 if (COUNTERS) c_rays++;
             }
         }
         if (ORT_BALLOT(ps != PS_DONE) == 0ull) break;
 
-        /* ---------------- closest hit: interruptible ordered DFS ---------------- */
+        /* ---------------- closest hit: interruptible ordered DFS ----------------
+         * while-while: every lane first descends interior nodes until it holds a leaf (or runs
+         * out of stack), then the wave processes leaves together, so the cheap box code and the
+         * expensive primitive code are not serialised against each other in every iteration.
+         * Slab test: the reference's own (p - o) * (1/d) form (ray.cpp:215-222) with ulp margins,
+         * conservative; fminf/fmaxf drop the NaN of 0 * inf, i.e. that axis is ignored. */
         while (tracing) {
+#if ORT_TRAV_WHILEWHILE
+            while (!(cur & LEAF_BIT)) {
+#else
             if (!(cur & LEAF_BIT)) {
-                const float4 *np = sv.nodes + 4u * cur;
+#endif
+                const float4 *np = sv.nodes + 4u * (cur & NODE_INDEX_MASK);
                 float4 a = np[0], b = np[1], c = np[2], d = np[3];
                 uint32_t c0 = om_f32_bits(d.x), c1 = om_f32_bits(d.y);
                 if (COUNTERS) c_nodes += 2;
-                /* conservative slab tests (same (p - o) * 1/d form as ray.cpp:215-222) */
+                /* the reference's own (p - o) * 1/d form (ray.cpp:215-222) with ulp margins */
                 float t0x = (a.x - org.x) * inv_d.x, t1x = (a.w - org.x) * inv_d.x;
                 float t0y = (a.y - org.y) * inv_d.y, t1y = (b.x - org.y) * inv_d.y;
                 float t0z = (a.z - org.z) * inv_d.z, t1z = (b.y - org.z) * inv_d.z;
@@ -460,38 +492,46 @@ ORT_D void pt_lane(const SceneView &sv, const RenderView &rv, uint32_t *lds_stac
                 float u0z = (c.x - org.z) * inv_d.z, u1z = (c.w - org.z) * inv_d.z;
                 float n1 = fmaxf(fmaxf(fminf(u0x, u1x), fminf(u0y, u1y)), fminf(u0z, u1z));
                 float f1 = fminf(fminf(fmaxf(u0x, u1x), fmaxf(u0y, u1y)), fmaxf(u0z, u1z));
-                bool h0 = (f0 * 1.0000004f >= n0) && (f0 >= 0.0f) && (n0 * 0.9999996f < best_t);
-                bool h1 = (f1 * 1.0000004f >= n1) && (f1 >= 0.0f) && (n1 * 0.9999996f < best_t) && (c1 != EMPTY_CHILD);
+                bool h0 = (f0 * 1.0000004f >= n0) && (f0 >= 0.0f) && ((n0 * 0.9999996f < best_t) || (c0 & SPHERE_BELOW_BIT));
+                bool h1 = (f1 * 1.0000004f >= n1) && (f1 >= 0.0f) && ((n1 * 0.9999996f < best_t) || (c1 & SPHERE_BELOW_BIT)) && (c1 != EMPTY_CHILD);
                 if (h0 && h1) {
                     bool swap = n1 < n0;
-                    uint32_t nearc = swap ? c1 : c0, farc = swap ? c0 : c1;
+                    uint32_t farc = swap ? c0 : c1;
+                    cur = swap ? c1 : c0;
                     if (sp < kLdsStack) lds_stack[sp * kBlock + tid] = farc;
                     else spill[sp - kLdsStack] = farc;
                     sp++;
-                    cur = nearc;
                 } else if (h0) {
                     cur = c0;
                 } else if (h1) {
                     cur = c1;
+                } else if (sp == 0) {
+                    cur = kTraversalDone;
                 } else {
-                    if (sp == 0) { tracing = false; }
-                    else {
-                        sp--;
-                        cur = (sp < kLdsStack) ? lds_stack[sp * kBlock + tid] : spill[sp - kLdsStack];
-                    }
+                    sp--;
+                    cur = (sp < kLdsStack) ? lds_stack[sp * kBlock + tid] : spill[sp - kLdsStack];
                 }
+            }
+#if ORT_TRAV_WHILEWHILE
+            if (cur == kTraversalDone) {
+#else
+            else if (cur == kTraversalDone) {
+#endif
+                tracing = false;
             } else {
                 uint32_t kind = (cur >> 28) & 7u, count = ((cur >> 24) & 15u) + 1u, first = cur & 0x00ffffffu;
                 for (uint32_t i = 0; i < count; ++i)
-                    test_prim<COUNTERS>(sv, kind, first + i, org, dir, best_t, hit_n, hit_prim, c_tris, c_analytic);
-                if (sp == 0) { tracing = false; }
-                else {
+                    test_prim<COUNTERS, false>(sv, kind, first + i, org, dir, inv_d, best_t, hit_n, hit_prim, phantom_t, c_tris, c_analytic);
+                if (sp == 0) {
+                    cur = kTraversalDone;
+                    tracing = false;
+                } else {
                     sp--;
                     cur = (sp < kLdsStack) ? lds_stack[sp * kBlock + tid] : spill[sp - kLdsStack];
                 }
             }
             /* when most of the wave has finished its ray, let the finished lanes shade and refill */
-            if (ORT_POPC64(ORT_BALLOT(tracing)) < 40) break;
+            if (ORT_POPC64(ORT_BALLOT(tracing)) < rv.refill_below) break;
         }
     }
 
@@ -501,8 +541,9 @@ ORT_D void pt_lane(const SceneView &sv, const RenderView &rv, uint32_t *lds_stac
         ORT_COUNT(rv.counters + 2, c_nodes);
         ORT_COUNT(rv.counters + 3, c_tris);
         ORT_COUNT(rv.counters + 4, c_analytic);
-        ORT_COUNT(rv.counters + 5, c_fallback);
     }
+    if (c_fallback) ORT_COUNT(rv.counters + 5, c_fallback);
+    if (overflow) ORT_COUNT(rv.counters + 6, 1ull);
 }
 
 /* pixel = (sum over k of partial[k], in k order) / nchunks for one pixel (CHUNK policy) */
@@ -525,10 +566,14 @@ ORT_D void combine_pixel(const RenderView &rv, unsigned long long idx) {
 }
 
 #ifndef ORT_HOST_SIM
+#ifndef ORT_WAVES_PER_EU
+#define ORT_WAVES_PER_EU 3 /* VGPR budget: 3 waves/SIMD = 168 registers (tuned on MI355X) */
+#endif
 template <bool COUNTERS>
-__global__ void __launch_bounds__(kBlock) pt_persistent(SceneView sv, RenderView rv) {
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(ORT_WAVES_PER_EU, ORT_WAVES_PER_EU)))
+pt_persistent(SceneView sv, RenderView rv) {
     __shared__ uint32_t lds_stack[kLdsStack * kBlock];
-    pt_lane<COUNTERS>(sv, rv, lds_stack, (int)threadIdx.x);
+    pt_lane<COUNTERS>(sv, rv, lds_stack, (int)threadIdx.x, blockIdx.x * (uint32_t)kBlock + threadIdx.x);
 }
 
 /* per-function evaluation on the device, for the parity tests: records of {u32 op; f32 in[24]}
@@ -550,8 +595,8 @@ __global__ void unit_eval(const uint32_t *records, uint32_t n, float *out) {
         o[0] = t;
         if (t >= 0.0f) { V3 c = cross(e1, e2); o[1] = c.x; o[2] = c.y; o[3] = c.z; }
     } break;
-    case 2: { float t = hit_sphere(in3(0), a[3], in3(4), in3(7), n3); o[0] = t; o[1] = n3.x; o[2] = n3.y; o[3] = n3.z; } break;
-    case 3: { float t = hit_aab(in3(0), in3(3), in3(6), in3(9), n3); o[0] = t; o[1] = n3.x; o[2] = n3.y; o[3] = n3.z; } break;
+    case 2: { bool tg; float t = hit_sphere(in3(0), a[3], in3(4), in3(7), n3, tg); o[0] = t; o[1] = n3.x; o[2] = n3.y; o[3] = n3.z; } break;
+    case 3: { V3 dd = in3(9); float t = hit_aab(in3(0), in3(3), in3(6), mk(1.0f / dd.x, 1.0f / dd.y, 1.0f / dd.z), n3); o[0] = t; o[1] = n3.x; o[2] = n3.y; o[3] = n3.z; } break;
     case 4: {
         /* host-precomputed frame arrives in a[13..22]: rot rows (9) + |axis| */
         float t = hit_cylinder(in3(0), a[6], in3(13), in3(16), in3(19), a[22], in3(7), in3(10), n3);
@@ -640,7 +685,7 @@ void device_release(Scene *scene) {
     (void)hipSetDevice(d->device);
     void *ptrs[] = {d->nodes, d->tris, d->tri_mat, d->spheres, d->sphere_mat, d->boxes, d->box_mat, d->cyls, d->cyl_mat,
                     d->materials, d->light_is_sphere, d->ref_nodes, d->ref_recs, d->chain_boxes, d->tri_chain, d->sphere_chain,
-                    d->box_chain, d->cyl_chain, d->tri_order, d->sphere_order, d->box_order, d->cyl_order, d->ctrl, d->partial, d->staging, d->jobs, d->states};
+                    d->box_chain, d->cyl_chain, d->tri_order, d->sphere_order, d->box_order, d->cyl_order, d->bfs_queue, d->ctrl, d->partial, d->staging, d->jobs, d->states};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (d->ev0) (void)hipEventDestroy(d->ev0);
@@ -705,6 +750,9 @@ int device_upload(Scene *scene, int device, std::string *err) {
     hipDeviceProp_t prop;
     ORT_HIP(hipGetDeviceProperties(&prop, device));
     d->cu_count = prop.multiProcessorCount;
+    /* persistent grid: 4 workgroups of 256 lanes per CU; one fallback ring per lane (8 KB, 2 GB total) */
+    d->max_blocks = (unsigned int)(d->cu_count > 0 ? d->cu_count : 256) * 4u;
+    ORT_HIP(hipMalloc(&d->bfs_queue, (size_t)d->max_blocks * kBlock * kBfsQueue * sizeof(uint32_t)));
     return ORT_OK;
 }
 
@@ -772,6 +820,7 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
     sv.box_chain = (const uint32_t *)d->box_chain; sv.cyl_chain = (const uint32_t *)d->cyl_chain;
     sv.tri_order = (const uint32_t *)d->tri_order; sv.sphere_order = (const uint32_t *)d->sphere_order;
     sv.box_order = (const uint32_t *)d->box_order; sv.cyl_order = (const uint32_t *)d->cyl_order;
+    sv.bfs_queue = (uint32_t *)d->bfs_queue;
     ort_camera cam;
     camera_basis(*scene, p->width, p->height, &cam);
     memcpy(sv.cam, &cam, sizeof(cam));
@@ -781,6 +830,12 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
     rv.x0 = p->x0; rv.y0 = p->y0; rv.x1 = p->x1; rv.y1 = p->y1;
     rv.seed = p->seed; rv.spp = p->spp; rv.chunk = p->chunk; rv.rr = p->rr;
     rv.out = out;
+    {
+        const char *e = getenv("ORT_REFILL_BELOW"); /* tuning knob; results do not depend on it */
+        rv.refill_below = e ? atoi(e) : 16; /* tuned on MI355X: profiles/r01_tuning.md */
+        if (rv.refill_below < 1) rv.refill_below = 1;
+        if (rv.refill_below > 64) rv.refill_below = 64;
+    }
     rv.next_job = d->ctrl;
     rv.counters = d->ctrl + 1;
     rv.shard_count = p->shard_count > 1 ? p->shard_count : 1;
@@ -816,7 +871,7 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
     ORT_HIP(hipMemsetAsync(d->ctrl, 0, 8 * sizeof(unsigned long long), stream));
     /* persistent grid: 4 blocks of 256 lanes per CU, never more lanes than jobs */
     unsigned long long lanes_wanted = rv.job_count;
-    unsigned int max_blocks = (unsigned int)(d->cu_count > 0 ? d->cu_count : 256) * 4u;
+    unsigned int max_blocks = d->max_blocks;
     unsigned int grid = (unsigned int)((lanes_wanted + kBlock - 1) / kBlock);
     if (grid > max_blocks) grid = max_blocks;
     if (grid == 0) grid = 1;
@@ -834,7 +889,14 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
 
     if (!d_out && h_out) ORT_HIP(hipMemcpyAsync(h_out, out, image_bytes, hipMemcpyDeviceToHost, stream));
     if (final_states) ORT_HIP(hipMemcpyAsync(final_states, d->states, (size_t)job_count * 4u, hipMemcpyDeviceToHost, stream));
-    if (stats || !d_out || final_states) ORT_HIP(hipStreamSynchronize(stream));
+    /* a fallback ring overflow must not go unnoticed: every synchronous form of the call checks it
+       (the fire-and-forget device form, stats == NULL, cannot without a sync; bench.py asks for stats) */
+    if (stats || !d_out || final_states) {
+        ORT_HIP(hipStreamSynchronize(stream));
+        unsigned long long ovf = 0;
+        ORT_HIP(hipMemcpy(&ovf, d->ctrl + 7, sizeof(ovf), hipMemcpyDeviceToHost));
+        if (ovf) { *err = "reference-order fallback queue overflowed (scene too deep for kBfsQueue)"; return ORT_ERR_UNSUPPORTED; }
+    }
     if (stats) {
         memset(stats, 0, sizeof(*stats));
         float ms = 0;

@@ -24,8 +24,8 @@ struct HostMesh {
  *
  * Node (64 B): a binary node carrying BOTH children's boxes, so one fetch decides both.
  *   lo0.xyz hi0.xyz lo1.xyz hi1.xyz child0 child1 pad pad
- * child word: bit31 = leaf.  interior: node index.  leaf: [30:28] primitive kind,
- *   [27:24] count-1, [23:0] first primitive index within that kind's array.
+ * child word: bit31 = leaf.  interior: [29:0] node index, bit30 = a sphere lives below.
+ *   leaf: [30:28] primitive kind, [27:24] count-1, [23:0] first index within that kind's array.
  */
 struct DevNode {
     float lo0[3], hi0[3], lo1[3], hi1[3];
@@ -33,8 +33,14 @@ struct DevNode {
 };
 static_assert(sizeof(DevNode) == 64, "node record must be 64 B");
 
-enum : uint32_t { PRIM_TRI = 0, PRIM_SPHERE = 1, PRIM_BOX = 2, PRIM_CYL = 3 };
+/* kind codes: SPHERE = 4 so that bit 30 of a leaf word means "sphere leaf"; interior child
+   words reuse bit 30 as "a sphere lives below".  Such children are exempt from the
+   closer-than-best cull: ray_intersect_with_sphere's tangent branch (ray.cpp:174-183) reports
+   t = -b/(2a), a point OUTSIDE the sphere's box and nearer than its entry distance. */
+enum : uint32_t { PRIM_TRI = 0, PRIM_BOX = 2, PRIM_CYL = 3, PRIM_SPHERE = 4 };
 constexpr uint32_t LEAF_BIT = 0x80000000u;
+constexpr uint32_t SPHERE_BELOW_BIT = 0x40000000u;
+constexpr uint32_t NODE_INDEX_MASK = 0x3fffffffu;
 constexpr uint32_t EMPTY_CHILD = 0xffffffffu; /* leaf, kind 7: never visited (box is inverted) */
 constexpr uint32_t MAX_LEAF_PRIMS = 16;
 

@@ -287,7 +287,7 @@ struct Builder {
         memcpy(n.lo0, lb.lo, 12); memcpy(n.hi0, lb.hi, 12);
         memcpy(n.lo1, rb.lo, 12); memcpy(n.hi1, rb.hi, 12);
         n.child0 = c0; n.child1 = c1;
-        return node_index;
+        return node_index | ((c0 | c1) & SPHERE_BELOW_BIT);
     }
 };
 
@@ -319,7 +319,9 @@ int build_tree(Scene *scene, std::string *err) {
         const ort_sphere &s = scene->spheres[i];
         Prim p;
         p.kind = PRIM_SPHERE; p.index = i;
-        float r = fabsf(s.r);
+        /* every ray the intersector can report a hit for passes within sqrt(r^2 + 1e-5) of the
+           centre (tangent branch, ray.cpp:145,174) */
+        float r = sqrtf(s.r * s.r + 0.00001f) * 1.00001f + 1e-6f;
         p.box.lo[0] = s.center.x - r; p.box.lo[1] = s.center.y - r; p.box.lo[2] = s.center.z - r;
         p.box.hi[0] = s.center.x + r; p.box.hi[1] = s.center.y + r; p.box.hi[2] = s.center.z + r;
         b.prims.push_back(p);
@@ -381,6 +383,7 @@ int build_tree(Scene *scene, std::string *err) {
         Box3 all = b.bounds(0, (uint32_t)b.prims.size());
         b.root_area = std::max(all.half_area(), 1e-30f);
         uint32_t root = b.build(0, (uint32_t)b.prims.size(), all, 0);
+        if (!(root & LEAF_BIT) && (root & NODE_INDEX_MASK) != 0) { *err = "internal: root is not node 0"; return ORT_ERR_INVALID; }
         if (root & LEAF_BIT) {
             DevNode n{};
             memcpy(n.lo0, all.lo, 12); memcpy(n.hi0, all.hi, 12);

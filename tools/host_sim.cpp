@@ -75,6 +75,7 @@ int main(int argc, char **argv) {
     RenderView rv{};
     rv.W = W; rv.H = H; rv.x0 = 0; rv.y0 = 0; rv.x1 = W; rv.y1 = H;
     rv.seed = seed; rv.spp = spp; rv.chunk = chunk; rv.rr = 0.8f;
+    rv.refill_below = 16;
     rv.out = out.data(); rv.next_job = ctrl; rv.counters = ctrl + 1;
     rv.shard_count = argc > 11 ? (uint32_t)atoi(argv[11]) : 1; rv.shard_index = argc > 11 ? (uint32_t)atoi(argv[10]) : 0;
     rv.blocks_w = (uint32_t)((W + 7) / 8);
@@ -105,11 +106,13 @@ int main(int argc, char **argv) {
     if (getenv("SIM_DUMP_RNG")) { g_pixel_rng = pix_rng.data(); g_W = W; }
     std::vector<uint32_t> lds(kLdsStack * kBlock);
     auto t0 = std::chrono::steady_clock::now();
-    pt_lane<true>(sv, rv, lds.data(), 0);
+    std::vector<uint32_t> bfsq(kBfsQueue);
+    sv.bfs_queue = bfsq.data();
+    pt_lane<true>(sv, rv, lds.data(), 0, 0);
     if (rv.mode == JOBS_CHUNK)
         for (unsigned long long i = 0; i < (unsigned long long)rv.my_blocks * 64; ++i) combine_pixel(rv, i);
     double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    fprintf(stderr, "sim: %.2fs paths %llu rays %llu node_tests %llu tri_tests %llu analytic %llu fallback %llu%s\n", sec, ctrl[1], ctrl[2], ctrl[3], ctrl[4], ctrl[5], ctrl[6],
+    fprintf(stderr, "sim: %.2fs paths %llu rays %llu node_tests %llu tri_tests %llu analytic %llu fallback %llu overflow %llu%s\n", sec, ctrl[1], ctrl[2], ctrl[3], ctrl[4], ctrl[5], ctrl[6], ctrl[7],
             finals.empty() ? "" : (" final_rng " + std::to_string(finals.back())).c_str());
     if (g_ray_log) fclose(g_ray_log);
     if (g_pixel_rng) { FILE *g = fopen(getenv("SIM_DUMP_RNG"), "wb"); fwrite(pix_rng.data(), 4, pix_rng.size(), g); fclose(g); }
