@@ -271,10 +271,8 @@ ORT_D void pt_lane(const SceneView &sv, const RenderView &rv, uint32_t *lds_stac
     int jx0 = 0, jx1 = 0, jy1 = 0, px = 0, py = 0;
     uint32_t spp = 0, sample = 0;
     float *dst = nullptr; /* where this job's pixels go (image or a partial plane) */
-    V3 color = mk(0, 0, 0), focal = mk(0, 0, 0);
+    V3 color = mk(0, 0, 0);
     V3 org = mk(0, 0, 0), dir = mk(0, 0, 0), wo = mk(0, 0, 0), weight = mk(1, 1, 1);
-    V3 surf_n = mk(0, 0, 0), prev_dir = mk(0, 0, 0);
-    uint32_t surf_mat = 0;
     bool primary = true;
 
     /* traversal state */
@@ -332,13 +330,8 @@ ORT_D void pt_lane(const SceneView &sv, const RenderView &rv, uint32_t *lds_stac
                     ps = PS_PIXEL;
                 }
                 if (ps == PS_PIXEL) {
-                    /* ray.cpp:1211-1221 */
                     ORT_SIM_PIXEL_HOOK(px, py, rng);
-                    color = mk(0, 0, 0);
-                    float fx = (2.0f * px / (float)rv.W) - 1.0f;
-                    float fy = (2.0f * py / (float)rv.H) - 1.0f;
-                    V3 to_pixel = normalize(sub(add(scale(fx, cam_x), scale(fy, cam_y)), cam_z));
-                    focal = add(cam_p, scale(focal_length, to_pixel));
+                    color = mk(0, 0, 0); /* ray.cpp:1211 */
                     sample = 0;
                     ps = PS_SAMPLE;
                 }
@@ -360,47 +353,31 @@ ORT_D void pt_lane(const SceneView &sv, const RenderView &rv, uint32_t *lds_stac
                     }
                     V3 n = normalize(hit_n);
                     ORT_SIM_RAY_HOOK(px, py, org, dir, best_t, n, hit_mat);
-                    if (primary) {
-                        if (COUNTERS) c_paths++;
-                        if (hit_mat) {
-                            Mat m = load_mat(sv.materials, hit_mat);
-                            if (m.is_light) {
-                                color = add(color, m.emit);
-                                alive = false;
-                            } else {
-                                org = add(org, scale(best_t - kEps, dir));
-                                surf_n = n;
-                                surf_mat = hit_mat;
-                                prev_dir = dir;
-                                if (len2(m.kd) > 0.0f) weight = had(weight, m.kd);
-                            }
-                        } else {
-                            alive = false; /* reference: undefined behaviour on a primary miss; defined: terminate */
-                        }
-                        primary = false;
+                    if (COUNTERS && primary) c_paths++;
+                    Mat m;
+                    if (hit_mat) m = load_mat(sv.materials, hit_mat);
+                    if (!hit_mat) {
+                        alive = false; /* bounce miss: ray.cpp:1418-1421; primary miss: undefined in the reference, defined: terminate */
+                    } else if (m.is_light) {
+                        /* ray.cpp:1254-1259 (primary: unweighted, unchecked) / :1358-1371 (bounce: dropped if not finite) */
+                        V3 c = primary ? m.emit : had(weight, m.emit);
+                        if (primary || (!isnan3(c) && !isinf3(c))) color = add(color, c);
+                        alive = false;
                     } else {
-                        if (hit_mat) {
-                            Mat m = load_mat(sv.materials, hit_mat);
-                            if (m.is_light) {
-                                V3 c = had(weight, m.emit);
-                                if (!isnan3(c) && !isinf3(c)) color = add(color, c);
-                                alive = false;
-                            } else {
-                                float p = pdf_brdf(n, dir, wo, kRoughness, m) * rv.rr;
-                                if (p > 0.000001f) {
-                                    V3 f = eval_scattering(n, dir, wo, m, kRoughness, best_t);
-                                    weight = had(divs(f, p), weight);
-                                }
-                                org = add(org, scale(best_t - kEps, dir));
-                                surf_n = n;
-                                surf_mat = hit_mat;
-                                prev_dir = dir;
-                                wo = neg(dir);
-                            }
+                        if (primary) {
+                            if (len2(m.kd) > 0.0f) weight = had(weight, m.kd); /* ray.cpp:1267-1270 */
                         } else {
-                            alive = false;
+                            /* ray.cpp:1374-1405: pdf and BSDF with the NEW surface's normal and material, the OLD wo (sic) */
+                            float p = pdf_brdf(n, dir, wo, kRoughness, m) * rv.rr;
+                            if (p > 0.000001f) {
+                                V3 f = eval_scattering(n, dir, wo, m, kRoughness, best_t);
+                                weight = had(divs(f, p), weight);
+                            }
+                            wo = neg(dir);
                         }
+                        org = add(org, scale(best_t - kEps, dir)); /* ray.cpp:1262,1411 */
                     }
+                    primary = false;
                     /* ray.cpp:1280: the roulette draw happens only while the path is alive */
                     if (alive && rng_01(rng) < rv.rr) {
                         /* sample_random_lights (ray.cpp:537-601): result unused, RNG advances */
@@ -409,10 +386,9 @@ ORT_D void pt_lane(const SceneView &sv, const RenderView &rv, uint32_t *lds_stac
                             uint32_t li = rng % sv.light_count;
                             if (sv.light_is_sphere[li]) { rng_step(rng); rng_step(rng); rng_step(rng); rng_step(rng); }
                         }
-                        Mat sm = load_mat(sv.materials, surf_mat);
                         bool is_trans;
-                        V3 wi = sample_brdf(rng, surf_n, wo, kRoughness, sm, is_trans);
-                        if (is_trans) org = add(org, scale(2.0f * kEps, prev_dir)); /* ray.cpp:1345-1348 */
+                        V3 wi = sample_brdf(rng, n, wo, kRoughness, m, is_trans);
+                        if (is_trans) org = add(org, scale(2.0f * kEps, dir)); /* ray.cpp:1345-1348: dir is still the arriving direction */
                         dir = wi;
                         tracing = true;
                         break;
@@ -436,6 +412,12 @@ ORT_D void pt_lane(const SceneView &sv, const RenderView &rv, uint32_t *lds_stac
                         }
                         continue;
                     }
+                    /* ray.cpp:1215-1221: point on the focal plane through the pixel centre (recomputed per
+                       sample instead of held in registers: same expressions, same bits) */
+                    float fx = (2.0f * px / (float)rv.W) - 1.0f;
+                    float fy = (2.0f * py / (float)rv.H) - 1.0f;
+                    V3 to_pixel = normalize(sub(add(scale(fx, cam_x), scale(fy, cam_y)), cam_z));
+                    V3 focal = add(cam_p, scale(focal_length, to_pixel));
                     /* ray.cpp:1232-1246 */
                     float rad = rng_between(rng, 0.0f, 2 * kPi);
                     V3 ap = sub(add(add(cam_p, scale(aperture * ort_cosf(rad), cam_x)), scale(aperture * ort_sinf(rad), cam_y)),
@@ -444,7 +426,6 @@ ORT_D void pt_lane(const SceneView &sv, const RenderView &rv, uint32_t *lds_stac
                     wo = neg(normalize(dir));
                     org = ap;
                     weight = mk(1, 1, 1);
-                    surf_mat = 0;
                     primary = true;
                     tracing = true;
                     break;
