@@ -111,14 +111,22 @@ def main():
 
     if not torch.cuda.is_available() or api.device_count() < 1:
         sys.exit("bench.py needs a HIP device: the render path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one process per GPU.  ORT_BENCH_SHARE_GPU=1 is a rehearsal mode for 1-GPU boxes: all ranks use
+    # device 0 and the gather goes through gloo on host copies (RCCL refuses two ranks on one device);
+    # the numbers of such a run mean nothing, it only exercises the N > 1 code path.
+    share_gpu = os.environ.get("ORT_BENCH_SHARE_GPU") == "1"
+    device_index = 0 if share_gpu else local_rank
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     scene_path = os.path.join(ROOT, "data", args.scene + ".scn")
-    scene = api.Scene.load_scn(scene_path).commit().upload(local_rank)
+    scene = api.Scene.load_scn(scene_path).commit().upload(device_index)
     W, H = args.width, args.height
     fb = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
     params = api.Scene.params(W, H, args.spp, args.seed, "chunk", chunk=args.chunk, shard=(rank, world))
@@ -127,7 +135,11 @@ def main():
     def step(want_stats=False):
         st = scene.render_device(fb.data_ptr(), params, stream=stream, want_stats=want_stats)
         if world > 1:
-            odist.gather_framebuffer(fb, W, H, rank, world)
+            if share_gpu:
+                torch.cuda.synchronize()
+                odist.gather_framebuffer(fb.cpu(), W, H, rank, world)
+            else:
+                odist.gather_framebuffer(fb, W, H, rank, world)
         return st
 
     def fence():
@@ -145,7 +157,7 @@ def main():
         kernel_ms.append(st["kernel_ms"])
     fence()
     elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cpu") if share_gpu else dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     ms_per_step = float(t.item()) / args.steps * 1e3

@@ -72,21 +72,33 @@ ORT_D uint32_t job_seed(uint32_t master, uint32_t job) {
     return h ? h : 1u;
 }
 
-/* ---- material record (DevMaterial, 4 x float4) ------------------------------------------- */
+/* ---- material record (DevMaterial, 5 x float4) ------------------------------------------- */
 struct Mat {
     V3 kd; float ior;
     V3 ks; uint32_t is_light;
-    V3 kt;
-    V3 emit;
+    V3 kt; float pd_c;  /* |Kd| / (|Kd|+|Ks|+|Kt|), ray.cpp:1016,1111 */
+    V3 emit; float ps_c;
+    V3 ed; float pt_c;  /* Kd / pi, ray.cpp:939 */
 };
 ORT_D Mat load_mat(const float4 *mats, uint32_t index) {
-    const float4 *p = mats + 4u * index;
-    float4 a = p[0], b = p[1], c = p[2], d = p[3];
+    const float4 *p = mats + 5u * index;
+    float4 a = p[0], b = p[1], c = p[2], d = p[3], e = p[4];
     Mat m;
     m.kd = mk(a.x, a.y, a.z); m.ior = a.w;
     m.ks = mk(b.x, b.y, b.z); m.is_light = om_f32_bits(b.w);
-    m.kt = mk(c.x, c.y, c.z);
-    m.emit = mk(d.x, d.y, d.z);
+    m.kt = mk(c.x, c.y, c.z); m.pd_c = c.w;
+    m.emit = mk(d.x, d.y, d.z); m.ps_c = d.w;
+    m.ed = mk(e.x, e.y, e.z); m.pt_c = e.w;
+    return m;
+}
+/* the same record from raw coefficients (unit tests): the per-material values as the reference computes them */
+ORT_D Mat make_mat(V3 kd, V3 ks, V3 kt, float ior) {
+    Mat m;
+    m.kd = kd; m.ks = ks; m.kt = kt; m.ior = ior; m.is_light = 0; m.emit = mk(0, 0, 0);
+    float a = len(kd), b = len(ks), c = len(kt);
+    float s = a + b + c;
+    m.pd_c = a / s; m.ps_c = b / s; m.pt_c = c / s;
+    m.ed = divs(kd, kPi);
     return m;
 }
 
@@ -130,16 +142,19 @@ ORT_D Beer beer(V3 N, V3 wo, float ior) {                                       
 }
 
 ORT_D V3 eval_scattering(V3 N, V3 wi, V3 wo, const Mat &mt, float rough, float dist) { /* ray.cpp:936-1005 */
-    V3 Ed = divs(mt.kd, kPi);
-    V3 H = scale(sgn(dot(wi, N)), normalize(add(wo, wi)));
-    float wi_h = dot(wi, H);
+    V3 Ed = mt.ed; /* Kd / pi_32, per material */
     V3 Es = mk(0, 0, 0), Et = mk(0, 0, 0);
     float wi_n = dot(wi, N), wo_n = dot(wo, N);
-    if (wi_h > 0.0f && len2(mt.ks) > 0.0f) {
+    /* H is only consumed under "wi.H > 0 && |Ks|^2 > 0" (ray.cpp:949): not computed for Ks = 0 */
+    if (len2(mt.ks) > 0.0f) {
+        V3 H = scale(sgn(dot(wi, N)), normalize(add(wo, wi)));
+        float wi_h = dot(wi, H);
+        if (wi_h > 0.0f) {
         V3 F = fresnel(mt.ks, wi_h);
         float D = ggx_d(N, H, rough);
         float G = geom(wi, N, H, rough) * geom(wo, N, H, rough);
         Es = scale((D * G) / (4.0f * absr(wi_n) * absr(wo_n)), F);
+        }
     }
     if (len2(mt.kt) > 0.0f) {
         V3 At = mk(1, 1, 1);
@@ -169,30 +184,30 @@ ORT_D V3 eval_scattering(V3 N, V3 wi, V3 wo, const Mat &mt, float rough, float d
 }
 
 ORT_D float pdf_brdf(V3 N, V3 wi, V3 wo, float rough, const Mat &mt) {            /* ray.cpp:1007-1063 */
-    float kd = len(mt.kd), ks = len(mt.ks), kt = len(mt.kt);
-    float s = kd + ks + kt;
-    float pd_c = kd / s, ps_c = ks / s, pt_c = kt / s;
+    float pd_c = mt.pd_c, ps_c = mt.ps_c, pt_c = mt.pt_c; /* per material, ray.cpp:1010-1018 */
     float pd = absr(dot(wi, N)) / kPi;
-    V3 H = scale(sgn(dot(N, wi)), normalize(add(wo, wi)));
-    float n_h = dot(N, H), wi_h = dot(wi, H);
     float ps = 0.0f;
-    if (ps_c > 0.0f) {
+    if (ps_c > 0.0f) { /* H and its dot products are only consumed here */
+        V3 H = scale(sgn(dot(N, wi)), normalize(add(wo, wi)));
+        float n_h = dot(N, H), wi_h = dot(wi, H);
         float denom = (4.0f * absr(wi_h));
         if (!ceq(denom, 0.0f)) {
             float D = ggx_d(N, H, rough);
             ps = D * absr(n_h) / denom;
         }
     }
-    Beer bn = beer(N, wo, mt.ior);
-    V3 m = normalize(neg(add(scale(bn.ni, wi), scale(bn.no, wo))));
-    float r = radicand(m, wo, bn.n);
     float pt = ps;                                                                /* sic */
-    if (pt_c > 0.0f && r >= 0.0f) {
-        float n_m = dot(N, m), wi_m = dot(wi, m), wo_m = dot(wo, m);
-        float denom = sq(bn.no * wo_m + bn.no * wo_m);                            /* sic, ray.cpp:1054 */
-        if (!ceq(denom, 0.0f)) {
-            float D = ggx_d(N, m, rough);
-            pt = D * absr(n_m) * sq(bn.no) * absr(wi_m) / denom;
+    if (pt_c > 0.0f) { /* m and the radicand are only consumed under "pt_c > 0 && r >= 0" */
+        Beer bn = beer(N, wo, mt.ior);
+        V3 m = normalize(neg(add(scale(bn.ni, wi), scale(bn.no, wo))));
+        float r = radicand(m, wo, bn.n);
+        if (r >= 0.0f) {
+            float n_m = dot(N, m), wi_m = dot(wi, m), wo_m = dot(wo, m);
+            float denom = sq(bn.no * wo_m + bn.no * wo_m);                        /* sic, ray.cpp:1054 */
+            if (!ceq(denom, 0.0f)) {
+                float D = ggx_d(N, m, rough);
+                pt = D * absr(n_m) * sq(bn.no) * absr(wi_m) / denom;
+            }
         }
     }
     return pd_c * pd + ps_c * ps + pt_c * pt;
@@ -210,9 +225,7 @@ ORT_D V3 sample_lobe(V3 N, float c, float phi) {                                
 }
 
 ORT_D V3 sample_brdf(uint32_t &rng, V3 N, V3 wo, float rough, const Mat &mt, bool &is_trans) { /* ray.cpp:1100-1161 */
-    float kd = len(mt.kd), ks = len(mt.ks), kt = len(mt.kt);
-    float s = kd + ks + kt;
-    float pd_c = kd / s, ps_c = ks / s;
+    float pd_c = mt.pd_c, ps_c = mt.ps_c; /* per material, ray.cpp:1105-1113 */
     float e0 = rng_01(rng), e1 = rng_01(rng), choice = rng_01(rng);
     V3 wi;
     is_trans = false;
@@ -221,10 +234,15 @@ ORT_D V3 sample_brdf(uint32_t &rng, V3 N, V3 wo, float rough, const Mat &mt, boo
     } else {
         float ct = ort_cosf(ort_atan2f(rough * __builtin_sqrtf(e0), __builtin_sqrtf(1.0f - e0)));
         V3 m = sample_lobe(N, ct, 2.0f * kPi * e1);
-        bool reflect = (choice >= pd_c && choice < pd_c + ps_c);
-        Beer bn = beer(N, wo, mt.ior);
-        float r = radicand(m, wo, bn.n);
-        if (reflect || r < 0.0f) {
+        bool refract = !(choice >= pd_c && choice < pd_c + ps_c);
+        Beer bn;
+        float r = 0.0f;
+        if (refract) {
+            bn = beer(N, wo, mt.ior);
+            r = radicand(m, wo, bn.n);
+            refract = !(r < 0.0f); /* total internal reflection falls back to the mirror direction */
+        }
+        if (!refract) {
             wi = sub(scale(2.0f * absr(dot(wo, m)), m), wo);
         } else {
             wi = sub(scale(bn.n * dot(wo, m) - sgn(dot(wo, N)) * __builtin_sqrtf(r), m), scale(bn.n, wo));

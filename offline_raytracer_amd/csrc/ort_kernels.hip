@@ -44,7 +44,7 @@ struct SceneView {
     const uint32_t *box_mat;
     const float4 *cyls;       /* 4 per cylinder */
     const uint32_t *cyl_mat;
-    const float4 *materials;  /* 4 per material */
+    const float4 *materials;  /* 5 per material (DevMaterial) */
     const uint32_t *light_is_sphere;
     uint32_t light_count;
     float cam[12];            /* p, x_axis, y_axis, z_axis */
@@ -123,6 +123,15 @@ enum : int { PS_NEED_JOB = 0, PS_PIXEL = 1, PS_SAMPLE = 2, PS_HIT = 3, PS_DONE =
 #endif
 
 
+/* ORT_STAMPS: diagnostic build only (tools/): per-phase cycle shares via s_memtime, written to
+   counters[8..11]; never defined in the product build */
+#if defined(ORT_STAMPS) && !defined(ORT_HOST_SIM)
+#define ORT_STAMP(var) unsigned long long var = __builtin_amdgcn_s_memtime()
+#define ORT_STAMP_ACC(acc, t0, t1) acc += (t1) - (t0)
+#else
+#define ORT_STAMP(var)
+#define ORT_STAMP_ACC(acc, t0, t1)
+#endif
 #ifndef ORT_TRAV_WHILEWHILE
 #define ORT_TRAV_WHILEWHILE 1
 #endif
@@ -188,18 +197,30 @@ ORT_D bool ref_node_admits(V3 lo, V3 hi, V3 org, V3 inv_d) {
     return hit_aab_t(lo, hi, org, inv_d) >= kHitTMin;
 }
 
-/* would the reference have reached this primitive?  Every node box on the way down must admit the ray. */
+/* would the reference have reached this primitive?  Every node box on the way down must admit the
+   ray.  Entries are fetched four at a time so the (divergent, L2-latency-bound) loads overlap. */
 ORT_D bool chain_admits(const SceneView &sv, uint32_t prim, V3 org, V3 inv_d) {
     uint32_t kind = prim >> 28, slot = prim & 0x00ffffffu;
     uint32_t word = (kind == PRIM_TRI) ? sv.tri_chain[slot]
                   : (kind == PRIM_SPHERE) ? sv.sphere_chain[slot]
                   : (kind == PRIM_BOX) ? sv.box_chain[slot] : sv.cyl_chain[slot];
     uint32_t len = word >> 28, first = word & 0x0fffffffu;
-    for (uint32_t i = 0; i < len; ++i) {
-        float4 lo = sv.chain_boxes[2u * (first + i)], hi = sv.chain_boxes[2u * (first + i) + 1u];
-        if (!ref_node_admits(mk(lo.x, lo.y, lo.z), mk(hi.x, hi.y, hi.z), org, inv_d)) return false;
+    bool ok = true;
+    for (uint32_t base = 0; base < len; base += 4u) {
+        float4 lo[4], hi[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) {
+            uint32_t i = base + k;
+            i = (i < len) ? i : (len - 1u); /* clamp: re-tests the last entry, harmless */
+            lo[k] = sv.chain_boxes[2u * (first + i)];
+            hi[k] = sv.chain_boxes[2u * (first + i) + 1u];
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k)
+            ok = ok && ref_node_admits(mk(lo[k].x, lo[k].y, lo[k].z), mk(hi[k].x, hi[k].y, hi[k].z), org, inv_d);
+        if (!ok) break;
     }
-    return true;
+    return ok;
 }
 
 /* exact fallback: raycast_bvh (ray.cpp:624-822) emulated literally on the reference-compatible
@@ -287,11 +308,16 @@ ORT_D void pt_lane(const SceneView &sv, const RenderView &rv, uint32_t *lds_stac
 
     unsigned long long c_paths = 0, c_rays = 0, c_nodes = 0, c_tris = 0, c_analytic = 0, c_fallback = 0;
 
+#if defined(ORT_STAMPS) && !defined(ORT_HOST_SIM)
+    unsigned long long st_shade = 0, st_descend = 0, st_leaf = 0, st_chain = 0, st_bsdf = 0, st_sample = 0, st_primary = 0, st_job = 0, st_pixend = 0, st_total0 = __builtin_amdgcn_s_memtime();
+#endif
     for (;;) {
+        ORT_STAMP(ts0);
         /* ---------------- produce the next ray (or run out of work) ---------------- */
         if (!tracing) {
             while (ps != PS_DONE) {
                 if (ps == PS_NEED_JOB) {
+                    ORT_STAMP(tj0);
                     unsigned long long j = ORT_NEXT_JOB(rv.next_job);
                     if (j >= rv.job_count) { ps = PS_DONE; break; }
                     if (rv.mode == JOBS_EXPLICIT) {
@@ -328,6 +354,8 @@ ORT_D void pt_lane(const SceneView &sv, const RenderView &rv, uint32_t *lds_stac
                         }
                     }
                     ps = PS_PIXEL;
+                    ORT_STAMP(tj1);
+                    ORT_STAMP_ACC(st_job, tj0, tj1);
                 }
                 if (ps == PS_PIXEL) {
                     ORT_SIM_PIXEL_HOOK(px, py, rng);
@@ -338,6 +366,7 @@ ORT_D void pt_lane(const SceneView &sv, const RenderView &rv, uint32_t *lds_stac
                 if (ps == PS_HIT) {
                     /* a traversal has finished: ray.cpp:817 then :1251-1277 (primary) or :1355-1421 (bounce) */
                     bool alive = true;
+                    ORT_STAMP(th0);
                     /* the reference only sees a shape through the node boxes above it (ray.cpp:788-803) */
                     if ((hit_prim != kNoPrim && !chain_admits(sv, hit_prim, org, inv_d)) || phantom_t <= best_t) {
                         c_fallback++;
@@ -351,6 +380,8 @@ ORT_D void pt_lane(const SceneView &sv, const RenderView &rv, uint32_t *lds_stac
                         hit_mat = (hk == PRIM_TRI) ? sv.tri_mat[hs] : (hk == PRIM_SPHERE) ? sv.sphere_mat[hs]
                                 : (hk == PRIM_BOX) ? sv.box_mat[hs] : sv.cyl_mat[hs];
                     }
+                    ORT_STAMP(th1);
+                    ORT_STAMP_ACC(st_chain, th0, th1);
                     V3 n = normalize(hit_n);
                     ORT_SIM_RAY_HOOK(px, py, org, dir, best_t, n, hit_mat);
                     if (COUNTERS && primary) c_paths++;
@@ -378,6 +409,8 @@ ORT_D void pt_lane(const SceneView &sv, const RenderView &rv, uint32_t *lds_stac
                         org = add(org, scale(best_t - kEps, dir)); /* ray.cpp:1262,1411 */
                     }
                     primary = false;
+                    ORT_STAMP(th2);
+                    ORT_STAMP_ACC(st_bsdf, th1, th2);
                     /* ray.cpp:1280: the roulette draw happens only while the path is alive */
                     if (alive && rng_01(rng) < rv.rr) {
                         /* sample_random_lights (ray.cpp:537-601): result unused, RNG advances */
@@ -391,6 +424,8 @@ ORT_D void pt_lane(const SceneView &sv, const RenderView &rv, uint32_t *lds_stac
                         if (is_trans) org = add(org, scale(2.0f * kEps, dir)); /* ray.cpp:1345-1348: dir is still the arriving direction */
                         dir = wi;
                         tracing = true;
+                        ORT_STAMP(th3);
+                        ORT_STAMP_ACC(st_sample, th2, th3);
                         break;
                     }
                     sample++;
@@ -398,6 +433,7 @@ ORT_D void pt_lane(const SceneView &sv, const RenderView &rv, uint32_t *lds_stac
                 }
                 if (ps == PS_SAMPLE) {
                     if (sample == spp) {
+                        ORT_STAMP(te0);
                         /* ray.cpp:1428 */
                         V3 o = divs(color, (float)spp);
                         float *p = dst + 3u * ((size_t)py * (size_t)rv.W + (size_t)px);
@@ -410,8 +446,11 @@ ORT_D void pt_lane(const SceneView &sv, const RenderView &rv, uint32_t *lds_stac
                         } else {
                             ps = PS_PIXEL;
                         }
+                        ORT_STAMP(te1);
+                        ORT_STAMP_ACC(st_pixend, te0, te1);
                         continue;
                     }
+                    ORT_STAMP(tp0);
                     /* ray.cpp:1215-1221: point on the focal plane through the pixel centre (recomputed per
                        sample instead of held in registers: same expressions, same bits) */
                     float fx = (2.0f * px / (float)rv.W) - 1.0f;
@@ -428,6 +467,8 @@ ORT_D void pt_lane(const SceneView &sv, const RenderView &rv, uint32_t *lds_stac
                     weight = mk(1, 1, 1);
                     primary = true;
                     tracing = true;
+                    ORT_STAMP(tp1);
+                    ORT_STAMP_ACC(st_primary, tp0, tp1);
                     break;
                 }
             }
@@ -445,6 +486,8 @@ ORT_D void pt_lane(const SceneView &sv, const RenderView &rv, uint32_t *lds_stac
             }
         }
         if (ORT_BALLOT(ps != PS_DONE) == 0ull) break;
+        ORT_STAMP(ts1);
+        ORT_STAMP_ACC(st_shade, ts0, ts1);
 
         /* ---------------- closest hit: interruptible ordered DFS ----------------
          * while-while: every lane first descends interior nodes until it holds a leaf (or runs
@@ -453,6 +496,7 @@ ORT_D void pt_lane(const SceneView &sv, const RenderView &rv, uint32_t *lds_stac
          * Slab test: the reference's own (p - o) * (1/d) form (ray.cpp:215-222) with ulp margins,
          * conservative; fminf/fmaxf drop the NaN of 0 * inf, i.e. that axis is ignored. */
         while (tracing) {
+            ORT_STAMP(td0);
 #if ORT_TRAV_WHILEWHILE
             while (!(cur & LEAF_BIT)) {
 #else
@@ -493,6 +537,8 @@ ORT_D void pt_lane(const SceneView &sv, const RenderView &rv, uint32_t *lds_stac
                     cur = (sp < kLdsStack) ? lds_stack[sp * kBlock + tid] : spill[sp - kLdsStack];
                 }
             }
+            ORT_STAMP(td1);
+            ORT_STAMP_ACC(st_descend, td0, td1);
 #if ORT_TRAV_WHILEWHILE
             if (cur == kTraversalDone) {
 #else
@@ -511,6 +557,8 @@ ORT_D void pt_lane(const SceneView &sv, const RenderView &rv, uint32_t *lds_stac
                     cur = (sp < kLdsStack) ? lds_stack[sp * kBlock + tid] : spill[sp - kLdsStack];
                 }
             }
+            ORT_STAMP(td2);
+            ORT_STAMP_ACC(st_leaf, td1, td2);
             /* when most of the wave has finished its ray, let the finished lanes shade and refill */
             if (ORT_POPC64(ORT_BALLOT(tracing)) < rv.refill_below) break;
         }
@@ -523,6 +571,20 @@ ORT_D void pt_lane(const SceneView &sv, const RenderView &rv, uint32_t *lds_stac
         ORT_COUNT(rv.counters + 3, c_tris);
         ORT_COUNT(rv.counters + 4, c_analytic);
     }
+#if defined(ORT_STAMPS) && !defined(ORT_HOST_SIM)
+    if ((tid & 63) == 0) {
+        atomicAdd(rv.counters + 8, st_shade);
+        atomicAdd(rv.counters + 9, st_descend);
+        atomicAdd(rv.counters + 10, st_leaf);
+        atomicAdd(rv.counters + 11, __builtin_amdgcn_s_memtime() - st_total0);
+        atomicAdd(rv.counters + 12, st_chain);
+        atomicAdd(rv.counters + 13, st_bsdf);
+        atomicAdd(rv.counters + 14, st_sample);
+        atomicAdd(rv.counters + 15, st_primary);
+        atomicAdd(rv.counters + 16, st_job);
+        atomicAdd(rv.counters + 17, st_pixend);
+    }
+#endif
     if (c_fallback) ORT_COUNT(rv.counters + 5, c_fallback);
     if (overflow) ORT_COUNT(rv.counters + 6, 1ull);
 }
@@ -585,17 +647,17 @@ __global__ void unit_eval(const uint32_t *records, uint32_t n, float *out) {
     } break;
     case 5: {
         uint32_t seed = om_f32_bits(a[0]);
-        Mat m; m.kd = in3(8); m.ks = in3(11); m.kt = in3(14); m.ior = a[17]; m.is_light = 0; m.emit = mk(0, 0, 0);
+        Mat m = make_mat(in3(8), in3(11), in3(14), a[17]);
         bool tr;
         V3 wi = sample_brdf(seed, in3(1), in3(4), a[7], m, tr);
         o[0] = wi.x; o[1] = wi.y; o[2] = wi.z; o[3] = tr ? 1.0f : 0.0f; o[4] = om_bits_f32(seed);
     } break;
     case 6: {
-        Mat m; m.kd = in3(10); m.ks = in3(13); m.kt = in3(16); m.ior = a[19]; m.is_light = 0; m.emit = mk(0, 0, 0);
+        Mat m = make_mat(in3(10), in3(13), in3(16), a[19]);
         o[0] = pdf_brdf(in3(0), in3(3), in3(6), a[9], m);
     } break;
     case 7: {
-        Mat m; m.kd = in3(9); m.ks = in3(12); m.kt = in3(15); m.ior = a[18]; m.is_light = 0; m.emit = mk(0, 0, 0);
+        Mat m = make_mat(in3(9), in3(12), in3(15), a[18]);
         V3 f = eval_scattering(in3(0), in3(3), in3(6), m, a[19], a[20]);
         o[0] = f.x; o[1] = f.y; o[2] = f.z;
     } break;
@@ -697,16 +759,7 @@ int device_upload(Scene *scene, int device, std::string *err) {
     if ((rc = upload_vec(t.cyls, &d->cyls, err))) return rc;
     if ((rc = upload_vec(t.cyl_mat, &d->cyl_mat, err))) return rc;
     std::vector<DevMaterial> mats(scene->materials.size());
-    for (size_t i = 0; i < mats.size(); ++i) {
-        const ort_material &m = scene->materials[i];
-        DevMaterial dm{};
-        dm.diffuse[0] = m.diffuse.x; dm.diffuse[1] = m.diffuse.y; dm.diffuse[2] = m.diffuse.z; dm.ior = m.ior;
-        dm.specular[0] = m.specular[0]; dm.specular[1] = m.specular[1]; dm.specular[2] = m.specular[2];
-        dm.is_light = m.is_light ? 1u : 0u;
-        dm.transmission[0] = m.transmission.x; dm.transmission[1] = m.transmission.y; dm.transmission[2] = m.transmission.z;
-        dm.emit[0] = m.emit.x; dm.emit[1] = m.emit.y; dm.emit[2] = m.emit.z;
-        mats[i] = dm;
-    }
+    for (size_t i = 0; i < mats.size(); ++i) mats[i] = make_dev_material(scene->materials[i]);
     if ((rc = upload_vec(mats, &d->materials, err))) return rc;
     std::vector<uint32_t> lis(scene->lights.size());
     for (size_t i = 0; i < lis.size(); ++i) lis[i] = (scene->lights[i].type == 1u) ? 1u : 0u;
@@ -724,8 +777,8 @@ int device_upload(Scene *scene, int device, std::string *err) {
     if ((rc = upload_vec(rt.sphere_order, &d->sphere_order, err))) return rc;
     if ((rc = upload_vec(rt.box_order, &d->box_order, err))) return rc;
     if ((rc = upload_vec(rt.cyl_order, &d->cyl_order, err))) return rc;
-    ORT_HIP(hipMalloc((void **)&d->ctrl, 8 * sizeof(unsigned long long)));
-    ORT_HIP(hipMemset(d->ctrl, 0, 8 * sizeof(unsigned long long)));
+    ORT_HIP(hipMalloc((void **)&d->ctrl, 24 * sizeof(unsigned long long)));
+    ORT_HIP(hipMemset(d->ctrl, 0, 24 * sizeof(unsigned long long)));
     ORT_HIP(hipEventCreate(&d->ev0));
     ORT_HIP(hipEventCreate(&d->ev1));
     hipDeviceProp_t prop;
@@ -849,7 +902,7 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
     }
 
     const bool counters = (p->flags & ORT_RENDER_COUNTERS) != 0;
-    ORT_HIP(hipMemsetAsync(d->ctrl, 0, 8 * sizeof(unsigned long long), stream));
+    ORT_HIP(hipMemsetAsync(d->ctrl, 0, 24 * sizeof(unsigned long long), stream));
     /* persistent grid: 4 blocks of 256 lanes per CU, never more lanes than jobs */
     unsigned long long lanes_wanted = rv.job_count;
     unsigned int max_blocks = d->max_blocks;
@@ -883,6 +936,16 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
         float ms = 0;
         ORT_HIP(hipEventElapsedTime(&ms, d->ev0, d->ev1));
         stats->kernel_ms = ms;
+#ifdef ORT_STAMPS
+        {
+            unsigned long long c[10];
+            ORT_HIP(hipMemcpy(c, d->ctrl + 9, sizeof(c), hipMemcpyDeviceToHost));
+            fprintf(stderr, "[stamps] job %.3f pixend %.3f\n", (double)c[8] / c[3], (double)c[9] / c[3]);
+            fprintf(stderr, "[stamps] shade %.3f (chain %.3f bsdf %.3f sample %.3f primary %.3f) descend %.3f leaf %.3f of wave time (%llu Mcycles)\n",
+                    (double)c[0] / c[3], (double)c[4] / c[3], (double)c[5] / c[3], (double)c[6] / c[3], (double)c[7] / c[3],
+                    (double)c[1] / c[3], (double)c[2] / c[3], c[3] / 1000000ull);
+        }
+#endif
         if (counters) {
             unsigned long long c[6];
             ORT_HIP(hipMemcpy(c, d->ctrl + 1, sizeof(c), hipMemcpyDeviceToHost));

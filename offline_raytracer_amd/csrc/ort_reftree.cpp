@@ -237,6 +237,10 @@ int build_ref_tree(Scene *scene, std::string *err) {
             uint32_t len = 0;
             for (int32_t a = (int32_t)ni; a > 0; a = b.nodes[(size_t)a].parent) {
                 const Node &an = b.nodes[(size_t)a];
+                if (len) { /* a node with one occupied child has that child's box: same test, keep one */
+                    const F4 &pl = out->chain_boxes[out->chain_boxes.size() - 2], &ph = out->chain_boxes[out->chain_boxes.size() - 1];
+                    if (pl.x == an.lo.x && pl.y == an.lo.y && pl.z == an.lo.z && ph.x == an.hi.x && ph.y == an.hi.y && ph.z == an.hi.z) continue;
+                }
                 out->chain_boxes.push_back(F4{an.lo.x, an.lo.y, an.lo.z, 0});
                 out->chain_boxes.push_back(F4{an.hi.x, an.hi.y, an.hi.z, 0});
                 ++len;

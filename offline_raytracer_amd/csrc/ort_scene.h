@@ -62,14 +62,19 @@ struct DevBox { float lo[3]; float pad0; float hi[3]; float pad1; }; /* 32 B */
 struct DevCyl { float base[3]; float r; float rot[9]; float len; float pad[2]; };
 static_assert(sizeof(DevCyl) == 64, "cylinder record must be 64 B");
 
-/* material as the path reads it (ray.h:30-40 minus specular.w), 64 B */
+/* material as the path reads it (ray.h:30-40 minus specular.w) plus the per-material values that
+   sample_brdf / pdf_brdf / eval_scattering recompute on every call (ray.cpp:939,1010-1018,
+   1105-1113): lobe weights |K|/(|Kd|+|Ks|+|Kt|) and Kd/pi, evaluated once on the host with the
+   reference's f32 expressions (same bits); 80 B */
 struct DevMaterial {
     float diffuse[3]; float ior;
     float specular[3]; uint32_t is_light;
-    float transmission[3]; float pad0;
-    float emit[3]; float pad1;
+    float transmission[3]; float pd_c;
+    float emit[3]; float ps_c;
+    float ed[3]; float pt_c;
 };
-static_assert(sizeof(DevMaterial) == 64, "material record must be 64 B");
+static_assert(sizeof(DevMaterial) == 80, "material record must be 80 B");
+DevMaterial make_dev_material(const ort_material &m); /* ort_tree.cpp */
 
 struct Tree {
     std::vector<DevNode> nodes;

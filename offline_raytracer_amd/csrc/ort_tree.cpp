@@ -10,6 +10,7 @@
  * run of 16-byte-aligned records of one kind, split by binned SAH.
  */
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -100,8 +101,8 @@ struct Builder {
     std::vector<TriRef> tri_refs;
     Tree *tree;
     static constexpr int kBins = 16;
-    static constexpr uint32_t kMaxLeafTri = 4;
-    static constexpr uint32_t kMaxLeafOther = 2;
+    uint32_t kMaxLeafTri = 4;   /* tuning knobs (env ORT_LEAF_TRI / ORT_LEAF_OTHER); results do not depend on them */
+    uint32_t kMaxLeafOther = 2;
     static constexpr uint32_t kDepthBudget = 60; /* traversal stack holds 64 entries */
     static constexpr float kNodeCost = 1.0f, kPrimCost = 1.2f;
     double sah_sum = 0;
@@ -293,6 +294,23 @@ struct Builder {
 
 } // namespace
 
+DevMaterial make_dev_material(const ort_material &m) {
+    DevMaterial d{};
+    d.diffuse[0] = m.diffuse.x; d.diffuse[1] = m.diffuse.y; d.diffuse[2] = m.diffuse.z; d.ior = m.ior;
+    d.specular[0] = m.specular[0]; d.specular[1] = m.specular[1]; d.specular[2] = m.specular[2];
+    d.is_light = m.is_light ? 1u : 0u;
+    d.transmission[0] = m.transmission.x; d.transmission[1] = m.transmission.y; d.transmission[2] = m.transmission.z;
+    d.emit[0] = m.emit.x; d.emit[1] = m.emit.y; d.emit[2] = m.emit.z;
+    /* ray.cpp:1010-1018: lengths, their sum, the three ratios (0/0 = NaN for an all-zero material, sic) */
+    float kd = v_len(d.diffuse), ks = v_len(d.specular), kt = v_len(d.transmission);
+    float s = kd + ks + kt;
+    d.pd_c = kd / s; d.ps_c = ks / s; d.pt_c = kt / s;
+    /* ray.cpp:939: Ed = Kd / pi_32, three divides */
+    const float pi_32 = 3.14159265358979323846264338327950288419716939937510582097494459230f;
+    d.ed[0] = d.diffuse[0] / pi_32; d.ed[1] = d.diffuse[1] / pi_32; d.ed[2] = d.diffuse[2] / pi_32;
+    return d;
+}
+
 void cylinder_frame_for(const ort_cylinder &c, float rot[9], float *len) { cylinder_frame(c, rot, len); }
 
 int build_tree(Scene *scene, std::string *err) {
@@ -382,7 +400,27 @@ int build_tree(Scene *scene, std::string *err) {
     } else {
         Box3 all = b.bounds(0, (uint32_t)b.prims.size());
         b.root_area = std::max(all.half_area(), 1e-30f);
-        uint32_t root = b.build(0, (uint32_t)b.prims.size(), all, 0);
+        if (const char *e = getenv("ORT_LEAF_TRI")) b.kMaxLeafTri = std::max(1, std::min((int)MAX_LEAF_PRIMS, atoi(e)));
+        if (const char *e = getenv("ORT_LEAF_OTHER")) b.kMaxLeafOther = std::max(1, std::min((int)MAX_LEAF_PRIMS, atoi(e)));
+        /* the few large analytic shapes (room boxes, lights) and the meshes get separate subtrees under
+           the root: the analytic side is visited first and usually fixes best_t before any mesh node */
+        const char *split_env = getenv("ORT_TREE_SPLIT_KINDS");
+        bool split_kinds = split_env ? atoi(split_env) != 0 : true;
+        uint32_t n_analytic = (uint32_t)(std::partition(b.prims.begin(), b.prims.end(), [](const Prim &p) { return p.kind != PRIM_TRI; }) - b.prims.begin());
+        uint32_t root;
+        if (split_kinds && n_analytic > 0 && n_analytic < b.prims.size()) {
+            tree->nodes.push_back(DevNode{});
+            Box3 ab = b.bounds(0, n_analytic), tb = b.bounds(n_analytic, (uint32_t)b.prims.size());
+            uint32_t c0 = b.build(0, n_analytic, ab, 1);
+            uint32_t c1 = b.build(n_analytic, (uint32_t)b.prims.size(), tb, 1);
+            DevNode &n = tree->nodes[0];
+            memcpy(n.lo0, ab.lo, 12); memcpy(n.hi0, ab.hi, 12);
+            memcpy(n.lo1, tb.lo, 12); memcpy(n.hi1, tb.hi, 12);
+            n.child0 = c0; n.child1 = c1;
+            root = (c0 | c1) & SPHERE_BELOW_BIT;
+        } else {
+            root = b.build(0, (uint32_t)b.prims.size(), all, 0);
+        }
         if (!(root & LEAF_BIT) && (root & NODE_INDEX_MASK) != 0) { *err = "internal: root is not node 0"; return ORT_ERR_INVALID; }
         if (root & LEAF_BIT) {
             DevNode n{};

@@ -151,6 +151,18 @@ def test_determinism(api, gpu_scene):
     assert_bits_equal(a, b)
 
 
+def test_phantom_sphere_hits(api, oracle, gpu_scene):
+    """ray_intersect_with_sphere's tangent branch (ray.cpp:174-183) reports t = -b/(2a): a hit in
+    mid-air, outside the sphere's box, whose visibility depends on the reference's visiting order.
+    The small mirror spheres of the analytic scene produce them; the kernel must agree exactly."""
+    scene = gpu_scene("c2_analytic")
+    w, h, spp = 160, 160, 16
+    img, st = scene.render(w, h, spp, 99, "chunk", chunk=4, counters=True)
+    ref, _ = oracle.OracleScene(scene.flatten(w, h)).render(w, h, spp, 99, "chunk", chunk=4, threads=16)
+    assert st["fallback_rays"] > 0
+    assert_bits_equal(img, ref)
+
+
 def test_exactness_fallback_is_exercised(api, oracle, gpu_scene):
     """some bounce origins land exactly on a reference octree node face; the kernel must then
     reproduce the reference's culling (Exactness).  Large enough to hit the case."""

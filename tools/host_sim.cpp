@@ -41,16 +41,7 @@ int main(int argc, char **argv) {
     fprintf(stderr, "tree: %u nodes, %u leaves, max leaf %u, depth %u, sah %.2f\n", ti.node_count, ti.leaf_count, ti.max_leaf_prims, ti.max_depth, ti.sah_cost);
 
     std::vector<DevMaterial> mats(scene->materials.size());
-    for (size_t i = 0; i < mats.size(); ++i) {
-        const ort_material &m = scene->materials[i];
-        DevMaterial dm{};
-        dm.diffuse[0] = m.diffuse.x; dm.diffuse[1] = m.diffuse.y; dm.diffuse[2] = m.diffuse.z; dm.ior = m.ior;
-        dm.specular[0] = m.specular[0]; dm.specular[1] = m.specular[1]; dm.specular[2] = m.specular[2];
-        dm.is_light = m.is_light ? 1u : 0u;
-        dm.transmission[0] = m.transmission.x; dm.transmission[1] = m.transmission.y; dm.transmission[2] = m.transmission.z;
-        dm.emit[0] = m.emit.x; dm.emit[1] = m.emit.y; dm.emit[2] = m.emit.z;
-        mats[i] = dm;
-    }
+    for (size_t i = 0; i < mats.size(); ++i) mats[i] = make_dev_material(scene->materials[i]);
     std::vector<uint32_t> lis(scene->lights.size());
     for (size_t i = 0; i < lis.size(); ++i) lis[i] = scene->lights[i].type == 1u;
 
