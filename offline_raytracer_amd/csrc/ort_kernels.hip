@@ -75,6 +75,22 @@ struct RenderView {
     unsigned long long *counters; /* paths rays node_tests tri_tests analytic_tests fallback_rays */
 };
 
+/* wavefront mode: per-slot path state in HBM, structure-of-arrays so that a wave's loads and
+   stores are coalesced (consecutive lanes = consecutive slots); 112 B per slot */
+struct WfView {
+    uint32_t slots;
+    float4 *od0;     /* org.xyz dir.x            (shade -> trace) */
+    float2 *od1;     /* dir.y dir.z */
+    float4 *hit0;    /* best_t hit_n.xyz         (trace -> shade) */
+    uint32_t *hitp;  /* hit_prim */
+    float4 *p0;      /* weight.xyz color.x       (shade -> shade) */
+    float4 *p1;      /* color.yz wo.xy */
+    float4 *p2;      /* wo.z rng sample spp */
+    uint4 *p3;       /* job_index  px|py<<16  jx0|jx1<<16  jy1|plane<<16 */
+    uint32_t *flags; /* bits 0-2 ps, bit 3 primary, bit 4 has a ray to trace */
+    unsigned long long *active; /* rays produced by the last counted shade launch */
+};
+
 struct DeviceScene {
     int device = -1;
     void *nodes = nullptr, *tris = nullptr, *tri_mat = nullptr, *spheres = nullptr, *sphere_mat = nullptr;
@@ -97,6 +113,9 @@ struct DeviceScene {
     size_t states_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int cu_count = 0;
+    void *wf_mem = nullptr; /* wavefront state, carved into the WfView arrays */
+    size_t wf_bytes = 0;
+    unsigned long long *h_active = nullptr; /* pinned */
 };
 
 /* ---- kernel ---------------------------------------------------------------------------- */
@@ -123,18 +142,10 @@ enum : int { PS_NEED_JOB = 0, PS_PIXEL = 1, PS_SAMPLE = 2, PS_HIT = 3, PS_DONE =
 #endif
 
 
-/* ORT_STAMPS: diagnostic build only (tools/): per-phase cycle shares via s_memtime, written to
-   counters[8..11]; never defined in the product build */
-#if defined(ORT_STAMPS) && !defined(ORT_HOST_SIM)
-#define ORT_STAMP(var) unsigned long long var = __builtin_amdgcn_s_memtime()
-#define ORT_STAMP_ACC(acc, t0, t1) acc += (t1) - (t0)
-#else
-#define ORT_STAMP(var)
-#define ORT_STAMP_ACC(acc, t0, t1)
-#endif
 #ifndef ORT_TRAV_WHILEWHILE
 #define ORT_TRAV_WHILEWHILE 1
 #endif
+
 constexpr uint32_t kNoPrim = 0xffffffffu;
 constexpr uint32_t kTraversalDone = 0xffffffffu; /* == EMPTY_CHILD: a leaf word no tree contains */
 
@@ -275,10 +286,54 @@ ORT_D bool ref_raycast_bfs(const SceneView &sv, V3 org, V3 dir, V3 inv_d, uint32
     return ok;
 }
 
-template <bool COUNTERS>
-ORT_D void pt_lane(const SceneView &sv, const RenderView &rv, uint32_t *lds_stack, const int tid, const uint32_t lane_id) {
-    uint32_t spill[kSpillStack];
+/* ---- the lane: path state, hit resolution, ray production, traversal ------------------------
+ * Shared by the two execution modes:
+ *   persistent: one kernel, every lane loops  produce_ray <-> traverse  (pt_persistent)
+ *   wavefront : path state lives in HBM; wf_shade runs produce_ray once per slot, wf_trace
+ *               runs traverse + resolve_hit once per slot, alternating over all slots. */
+struct Counters {
+    unsigned long long paths = 0, rays = 0, nodes = 0, tris = 0, analytic = 0, fallback = 0;
+    bool overflow = false;
+};
 
+struct PathState {
+    int ps = PS_NEED_JOB;
+    uint32_t rng = 0, job_index = 0;
+    int jx0 = 0, jx1 = 0, jy1 = 0, px = 0, py = 0;
+    uint32_t spp = 0, sample = 0;
+    uint32_t plane = 0; /* CHUNK policy: which partial plane this job writes */
+    V3 color, org, dir, wo, weight;
+    bool primary = true;
+};
+
+struct HitState {
+    float best_t = 0;
+    V3 hit_n;
+    uint32_t hit_prim = kNoPrim;
+    float phantom_t = 0;
+};
+
+ORT_D float *job_plane(const RenderView &rv, uint32_t plane) {
+    return (rv.mode == JOBS_CHUNK) ? rv.partial + (size_t)plane * (size_t)rv.W * (size_t)rv.H * 3u : rv.out;
+}
+
+/* After a traversal: would the reference have seen this winner (ray.cpp:788-803)?  If not, or if a
+   phantom tangent hit could have won, re-cast the ray exactly. */
+template <bool COUNTERS>
+ORT_D void resolve_hit(const SceneView &sv, V3 org, V3 dir, V3 inv_d, uint32_t lane_id, HitState &h, Counters &c) {
+    if ((h.hit_prim != kNoPrim && !chain_admits(sv, h.hit_prim, org, inv_d)) || h.phantom_t <= h.best_t) {
+        c.fallback++;
+        if (!ref_raycast_bfs<COUNTERS>(sv, org, dir, inv_d, sv.bfs_queue + (size_t)lane_id * kBfsQueue, h.best_t, h.hit_n, h.hit_prim,
+                                       c.nodes, c.tris, c.analytic))
+            c.overflow = true;
+    }
+}
+
+/* Advance the lane's path state machine until it has produced the next ray (returns true; the ray
+   is P.org / P.dir) or has run out of work (returns false).  On entry with P.ps == PS_HIT, h holds
+   the resolved closest hit of the ray produced by the previous call. */
+template <bool COUNTERS>
+ORT_D bool produce_ray(const SceneView &sv, const RenderView &rv, PathState &P, const HitState &h, Counters &c) {
     const V3 cam_p = mk(sv.cam[0], sv.cam[1], sv.cam[2]);
     const V3 cam_x = mk(sv.cam[3], sv.cam[4], sv.cam[5]);
     const V3 cam_y = mk(sv.cam[6], sv.cam[7], sv.cam[8]);
@@ -286,307 +341,337 @@ ORT_D void pt_lane(const SceneView &sv, const RenderView &rv, uint32_t *lds_stac
     const float focal_length = len(sub(cam_p, mk(0, 0, 0.2f))); /* ray.cpp:1198 */
     const float aperture = 0.1f;                                /* ray.cpp:1199 */
 
-    /* path state */
-    int ps = PS_NEED_JOB;
-    uint32_t rng = 0, job_index = 0;
-    int jx0 = 0, jx1 = 0, jy1 = 0, px = 0, py = 0;
-    uint32_t spp = 0, sample = 0;
-    float *dst = nullptr; /* where this job's pixels go (image or a partial plane) */
-    V3 color = mk(0, 0, 0);
-    V3 org = mk(0, 0, 0), dir = mk(0, 0, 0), wo = mk(0, 0, 0), weight = mk(1, 1, 1);
-    bool primary = true;
+    while (P.ps != PS_DONE) {
+        if (P.ps == PS_NEED_JOB) {
+            unsigned long long j = ORT_NEXT_JOB(rv.next_job);
+            if (j >= rv.job_count) { P.ps = PS_DONE; break; }
+            if (rv.mode == JOBS_EXPLICIT) {
+                ort_tile_job jb = rv.jobs[j];
+                P.job_index = (uint32_t)j;
+                P.jx0 = jb.x0; P.jx1 = jb.x1; P.jy1 = jb.y1;
+                P.px = jb.x0; P.py = jb.y0;
+                P.rng = jb.rng_state; P.spp = jb.spp;
+                P.plane = 0;
+                if (jb.x1 <= jb.x0 || jb.y1 <= jb.y0) { /* empty rect: the reference loops zero times */
+                    if (rv.final_states) rv.final_states[P.job_index] = P.rng;
+                    continue;
+                }
+            } else {
+                /* implicit job space: [chunk k][my 8x8 block b][pixel-in-block p] */
+                unsigned long long per_chunk = (unsigned long long)rv.my_blocks * 64ull;
+                uint32_t k = (uint32_t)(j / per_chunk);
+                uint32_t rem = (uint32_t)(j % per_chunk);
+                uint32_t blk = rv.shard_index + (rem >> 6) * rv.shard_count;
+                uint32_t pin = rem & 63u;
+                int x = (int)((blk % rv.blocks_w) * 8u + (pin & 7u));
+                int y = (int)((blk / rv.blocks_w) * 8u + (pin >> 3));
+                if (x < rv.x0 || x >= rv.x1 || y < rv.y0 || y >= rv.y1) continue;
+                uint32_t pix = (uint32_t)(y * rv.W + x);
+                P.jx0 = x; P.jx1 = x + 1; P.jy1 = y + 1; P.px = x; P.py = y;
+                if (rv.mode == JOBS_PIXEL) {
+                    P.rng = job_seed(rv.seed, pix);
+                    P.spp = rv.spp;
+                    P.plane = 0;
+                } else {
+                    P.rng = job_seed(rv.seed, k * (uint32_t)(rv.W * rv.H) + pix);
+                    P.spp = rv.chunk;
+                    P.plane = k;
+                }
+            }
+            P.ps = PS_PIXEL;
+        }
+        if (P.ps == PS_PIXEL) {
+            ORT_SIM_PIXEL_HOOK(P.px, P.py, P.rng);
+            P.color = mk(0, 0, 0); /* ray.cpp:1211 */
+            P.sample = 0;
+            P.ps = PS_SAMPLE;
+        }
+        if (P.ps == PS_HIT) {
+            /* a traversal has finished: ray.cpp:817 then :1251-1277 (primary) or :1355-1421 (bounce) */
+            bool alive = true;
+            uint32_t hit_mat = 0;
+            if (h.hit_prim != kNoPrim) {
+                uint32_t hk = h.hit_prim >> 28, hs = h.hit_prim & 0x00ffffffu;
+                hit_mat = (hk == PRIM_TRI) ? sv.tri_mat[hs] : (hk == PRIM_SPHERE) ? sv.sphere_mat[hs]
+                        : (hk == PRIM_BOX) ? sv.box_mat[hs] : sv.cyl_mat[hs];
+            }
+            V3 n = normalize(h.hit_n);
+            ORT_SIM_RAY_HOOK(P.px, P.py, P.org, P.dir, h.best_t, n, hit_mat);
+            if (COUNTERS && P.primary) c.paths++;
+            Mat m;
+            if (hit_mat) m = load_mat(sv.materials, hit_mat);
+            if (!hit_mat) {
+                alive = false; /* bounce miss: ray.cpp:1418-1421; primary miss: undefined in the reference, defined: terminate */
+            } else if (m.is_light) {
+                /* ray.cpp:1254-1259 (primary: unweighted, unchecked) / :1358-1371 (bounce: dropped if not finite) */
+                V3 e = P.primary ? m.emit : had(P.weight, m.emit);
+                if (P.primary || (!isnan3(e) && !isinf3(e))) P.color = add(P.color, e);
+                alive = false;
+            } else {
+                if (P.primary) {
+                    if (len2(m.kd) > 0.0f) P.weight = had(P.weight, m.kd); /* ray.cpp:1267-1270 */
+                } else {
+                    /* ray.cpp:1374-1405: pdf and BSDF with the NEW surface's normal and material, the OLD wo (sic) */
+                    float p = pdf_brdf(n, P.dir, P.wo, kRoughness, m) * rv.rr;
+                    if (p > 0.000001f) {
+                        V3 f = eval_scattering(n, P.dir, P.wo, m, kRoughness, h.best_t);
+                        P.weight = had(divs(f, p), P.weight);
+                    }
+                    P.wo = neg(P.dir);
+                }
+                P.org = add(P.org, scale(h.best_t - kEps, P.dir)); /* ray.cpp:1262,1411 */
+            }
+            P.primary = false;
+            /* ray.cpp:1280: the roulette draw happens only while the path is alive */
+            if (alive && rng_01(P.rng) < rv.rr) {
+                /* sample_random_lights (ray.cpp:537-601): result unused, RNG advances */
+                rng_step(P.rng);
+                if (sv.light_count) {
+                    uint32_t li = P.rng % sv.light_count;
+                    if (sv.light_is_sphere[li]) { rng_step(P.rng); rng_step(P.rng); rng_step(P.rng); rng_step(P.rng); }
+                }
+                bool is_trans;
+                V3 wi = sample_brdf(P.rng, n, P.wo, kRoughness, m, is_trans);
+                if (is_trans) P.org = add(P.org, scale(2.0f * kEps, P.dir)); /* ray.cpp:1345-1348: dir is still the arriving direction */
+                P.dir = wi;
+                return true;
+            }
+            P.sample++;
+            P.ps = PS_SAMPLE;
+        }
+        if (P.ps == PS_SAMPLE) {
+            if (P.sample == P.spp) {
+                /* ray.cpp:1428 */
+                V3 o = divs(P.color, (float)P.spp);
+                float *p = job_plane(rv, P.plane) + 3u * ((size_t)P.py * (size_t)rv.W + (size_t)P.px);
+                p[0] = o.x; p[1] = o.y; p[2] = o.z;
+                P.px++;
+                if (P.px == P.jx1) { P.px = P.jx0; P.py++; }
+                if (P.py == P.jy1) {
+                    if (rv.mode == JOBS_EXPLICIT && rv.final_states) rv.final_states[P.job_index] = P.rng;
+                    P.ps = PS_NEED_JOB;
+                } else {
+                    P.ps = PS_PIXEL;
+                }
+                continue;
+            }
+            /* ray.cpp:1215-1221: point on the focal plane through the pixel centre (recomputed per
+               sample instead of held in registers: same expressions, same bits) */
+            float fx = (2.0f * P.px / (float)rv.W) - 1.0f;
+            float fy = (2.0f * P.py / (float)rv.H) - 1.0f;
+            V3 to_pixel = normalize(sub(add(scale(fx, cam_x), scale(fy, cam_y)), cam_z));
+            V3 focal = add(cam_p, scale(focal_length, to_pixel));
+            /* ray.cpp:1232-1246 */
+            float rad = rng_between(P.rng, 0.0f, 2 * kPi);
+            V3 ap = sub(add(add(cam_p, scale(aperture * ort_cosf(rad), cam_x)), scale(aperture * ort_sinf(rad), cam_y)),
+                        scale(0.1f, cam_z));
+            P.dir = normalize(sub(focal, ap));
+            P.wo = neg(normalize(P.dir));
+            P.org = ap;
+            P.weight = mk(1, 1, 1);
+            P.primary = true;
+            P.ps = PS_HIT;
+            return true;
+        }
+    }
+    return false;
+}
 
-    /* traversal state */
-    bool tracing = false;
+/* traversal state of one ray on the fast tree */
+struct Trav {
     uint32_t cur = 0;
     int sp = 0;
-    float best_t = 0;
-    V3 hit_n = mk(0, 0, 0), inv_d = mk(0, 0, 0);
-    uint32_t hit_prim = kNoPrim;
-    float phantom_t = 0;
-    bool overflow = false;
+    V3 inv_d;
+};
 
-    unsigned long long c_paths = 0, c_rays = 0, c_nodes = 0, c_tris = 0, c_analytic = 0, c_fallback = 0;
+ORT_D void begin_ray(const PathState &P, Trav &T, HitState &h) {
+    /* raycast_top_most_node (ray.cpp:1165-1176): start at the root */
+    T.cur = 0;
+    T.sp = 0;
+    T.inv_d = mk(1.0f / P.dir.x, 1.0f / P.dir.y, 1.0f / P.dir.z); /* ray.cpp:210, once per ray */
+    h.best_t = 3.402823466e+38f; /* Flt_Max, ray.cpp:627 */
+    h.hit_n = mk(0, 0, 0);
+    h.hit_prim = kNoPrim;
+    h.phantom_t = __builtin_inff(); /* none yet; compared with <= against best_t (<= FLT_MAX) */
+}
 
-#if defined(ORT_STAMPS) && !defined(ORT_HOST_SIM)
-    unsigned long long st_shade = 0, st_descend = 0, st_leaf = 0, st_chain = 0, st_bsdf = 0, st_sample = 0, st_primary = 0, st_job = 0, st_pixend = 0, st_total0 = __builtin_amdgcn_s_memtime();
+/* Closest hit: interruptible ordered DFS, replaces raycast_bvh (ray.cpp:624-822) on the fast tree.
+ * while-while: a lane first descends interior nodes until it holds a leaf (or runs out of stack),
+ * then the wave processes leaves together, so the cheap box code and the expensive primitive code
+ * are not serialised against each other in every iteration.
+ * Slab test: the reference's own (p - o) * (1/d) form (ray.cpp:215-222) with ulp margins,
+ * conservative; fminf/fmaxf drop the NaN of 0 * inf, i.e. that axis is ignored.
+ * Returns when this lane's ray is finished, or -- refill_below > 0 -- as soon as fewer than
+ * refill_below lanes of the wave are still traversing (the caller resumes later: all state is in T/h). */
+template <bool COUNTERS, int LDS_ENTRIES, int BLOCK>
+ORT_D bool traverse(const SceneView &sv, V3 org, V3 dir, Trav &T, HitState &h, uint32_t *lds_stack, uint32_t *spill, int tid,
+                    int refill_below, Counters &c) {
+    bool tracing = true;
+    uint32_t cur = T.cur;
+    int sp = T.sp;
+    const V3 inv_d = T.inv_d;
+    while (tracing) {
+#if ORT_TRAV_WHILEWHILE
+        while (!(cur & LEAF_BIT)) {
+#else
+        if (!(cur & LEAF_BIT)) {
 #endif
-    for (;;) {
-        ORT_STAMP(ts0);
-        /* ---------------- produce the next ray (or run out of work) ---------------- */
-        if (!tracing) {
-            while (ps != PS_DONE) {
-                if (ps == PS_NEED_JOB) {
-                    ORT_STAMP(tj0);
-                    unsigned long long j = ORT_NEXT_JOB(rv.next_job);
-                    if (j >= rv.job_count) { ps = PS_DONE; break; }
-                    if (rv.mode == JOBS_EXPLICIT) {
-                        ort_tile_job jb = rv.jobs[j];
-                        job_index = (uint32_t)j;
-                        jx0 = jb.x0; jx1 = jb.x1; jy1 = jb.y1;
-                        px = jb.x0; py = jb.y0;
-                        rng = jb.rng_state; spp = jb.spp;
-                        dst = rv.out;
-                        if (jb.x1 <= jb.x0 || jb.y1 <= jb.y0) { /* empty rect: the reference loops zero times */
-                            if (rv.final_states) rv.final_states[job_index] = rng;
-                            continue;
-                        }
-                    } else {
-                        /* implicit job space: [chunk k][my 8x8 block b][pixel-in-block p] */
-                        unsigned long long per_chunk = (unsigned long long)rv.my_blocks * 64ull;
-                        uint32_t k = (uint32_t)(j / per_chunk);
-                        uint32_t rem = (uint32_t)(j % per_chunk);
-                        uint32_t blk = rv.shard_index + (rem >> 6) * rv.shard_count;
-                        uint32_t pin = rem & 63u;
-                        int x = (int)((blk % rv.blocks_w) * 8u + (pin & 7u));
-                        int y = (int)((blk / rv.blocks_w) * 8u + (pin >> 3));
-                        if (x < rv.x0 || x >= rv.x1 || y < rv.y0 || y >= rv.y1) continue;
-                        uint32_t pix = (uint32_t)(y * rv.W + x);
-                        jx0 = x; jx1 = x + 1; jy1 = y + 1; px = x; py = y;
-                        if (rv.mode == JOBS_PIXEL) {
-                            rng = job_seed(rv.seed, pix);
-                            spp = rv.spp;
-                            dst = rv.out;
-                        } else {
-                            rng = job_seed(rv.seed, k * (uint32_t)(rv.W * rv.H) + pix);
-                            spp = rv.chunk;
-                            dst = rv.partial + (size_t)k * (size_t)rv.W * (size_t)rv.H * 3u;
-                        }
-                    }
-                    ps = PS_PIXEL;
-                    ORT_STAMP(tj1);
-                    ORT_STAMP_ACC(st_job, tj0, tj1);
-                }
-                if (ps == PS_PIXEL) {
-                    ORT_SIM_PIXEL_HOOK(px, py, rng);
-                    color = mk(0, 0, 0); /* ray.cpp:1211 */
-                    sample = 0;
-                    ps = PS_SAMPLE;
-                }
-                if (ps == PS_HIT) {
-                    /* a traversal has finished: ray.cpp:817 then :1251-1277 (primary) or :1355-1421 (bounce) */
-                    bool alive = true;
-                    ORT_STAMP(th0);
-                    /* the reference only sees a shape through the node boxes above it (ray.cpp:788-803) */
-                    if ((hit_prim != kNoPrim && !chain_admits(sv, hit_prim, org, inv_d)) || phantom_t <= best_t) {
-                        c_fallback++;
-                        if (!ref_raycast_bfs<COUNTERS>(sv, org, dir, inv_d, sv.bfs_queue + (size_t)lane_id * kBfsQueue, best_t, hit_n,
-                                                       hit_prim, c_nodes, c_tris, c_analytic))
-                            overflow = true;
-                    }
-                    uint32_t hit_mat = 0;
-                    if (hit_prim != kNoPrim) {
-                        uint32_t hk = hit_prim >> 28, hs = hit_prim & 0x00ffffffu;
-                        hit_mat = (hk == PRIM_TRI) ? sv.tri_mat[hs] : (hk == PRIM_SPHERE) ? sv.sphere_mat[hs]
-                                : (hk == PRIM_BOX) ? sv.box_mat[hs] : sv.cyl_mat[hs];
-                    }
-                    ORT_STAMP(th1);
-                    ORT_STAMP_ACC(st_chain, th0, th1);
-                    V3 n = normalize(hit_n);
-                    ORT_SIM_RAY_HOOK(px, py, org, dir, best_t, n, hit_mat);
-                    if (COUNTERS && primary) c_paths++;
-                    Mat m;
-                    if (hit_mat) m = load_mat(sv.materials, hit_mat);
-                    if (!hit_mat) {
-                        alive = false; /* bounce miss: ray.cpp:1418-1421; primary miss: undefined in the reference, defined: terminate */
-                    } else if (m.is_light) {
-                        /* ray.cpp:1254-1259 (primary: unweighted, unchecked) / :1358-1371 (bounce: dropped if not finite) */
-                        V3 c = primary ? m.emit : had(weight, m.emit);
-                        if (primary || (!isnan3(c) && !isinf3(c))) color = add(color, c);
-                        alive = false;
-                    } else {
-                        if (primary) {
-                            if (len2(m.kd) > 0.0f) weight = had(weight, m.kd); /* ray.cpp:1267-1270 */
-                        } else {
-                            /* ray.cpp:1374-1405: pdf and BSDF with the NEW surface's normal and material, the OLD wo (sic) */
-                            float p = pdf_brdf(n, dir, wo, kRoughness, m) * rv.rr;
-                            if (p > 0.000001f) {
-                                V3 f = eval_scattering(n, dir, wo, m, kRoughness, best_t);
-                                weight = had(divs(f, p), weight);
-                            }
-                            wo = neg(dir);
-                        }
-                        org = add(org, scale(best_t - kEps, dir)); /* ray.cpp:1262,1411 */
-                    }
-                    primary = false;
-                    ORT_STAMP(th2);
-                    ORT_STAMP_ACC(st_bsdf, th1, th2);
-                    /* ray.cpp:1280: the roulette draw happens only while the path is alive */
-                    if (alive && rng_01(rng) < rv.rr) {
-                        /* sample_random_lights (ray.cpp:537-601): result unused, RNG advances */
-                        rng_step(rng);
-                        if (sv.light_count) {
-                            uint32_t li = rng % sv.light_count;
-                            if (sv.light_is_sphere[li]) { rng_step(rng); rng_step(rng); rng_step(rng); rng_step(rng); }
-                        }
-                        bool is_trans;
-                        V3 wi = sample_brdf(rng, n, wo, kRoughness, m, is_trans);
-                        if (is_trans) org = add(org, scale(2.0f * kEps, dir)); /* ray.cpp:1345-1348: dir is still the arriving direction */
-                        dir = wi;
-                        tracing = true;
-                        ORT_STAMP(th3);
-                        ORT_STAMP_ACC(st_sample, th2, th3);
-                        break;
-                    }
-                    sample++;
-                    ps = PS_SAMPLE;
-                }
-                if (ps == PS_SAMPLE) {
-                    if (sample == spp) {
-                        ORT_STAMP(te0);
-                        /* ray.cpp:1428 */
-                        V3 o = divs(color, (float)spp);
-                        float *p = dst + 3u * ((size_t)py * (size_t)rv.W + (size_t)px);
-                        p[0] = o.x; p[1] = o.y; p[2] = o.z;
-                        px++;
-                        if (px == jx1) { px = jx0; py++; }
-                        if (py == jy1) {
-                            if (rv.mode == JOBS_EXPLICIT && rv.final_states) rv.final_states[job_index] = rng;
-                            ps = PS_NEED_JOB;
-                        } else {
-                            ps = PS_PIXEL;
-                        }
-                        ORT_STAMP(te1);
-                        ORT_STAMP_ACC(st_pixend, te0, te1);
-                        continue;
-                    }
-                    ORT_STAMP(tp0);
-                    /* ray.cpp:1215-1221: point on the focal plane through the pixel centre (recomputed per
-                       sample instead of held in registers: same expressions, same bits) */
-                    float fx = (2.0f * px / (float)rv.W) - 1.0f;
-                    float fy = (2.0f * py / (float)rv.H) - 1.0f;
-                    V3 to_pixel = normalize(sub(add(scale(fx, cam_x), scale(fy, cam_y)), cam_z));
-                    V3 focal = add(cam_p, scale(focal_length, to_pixel));
-                    /* ray.cpp:1232-1246 */
-                    float rad = rng_between(rng, 0.0f, 2 * kPi);
-                    V3 ap = sub(add(add(cam_p, scale(aperture * ort_cosf(rad), cam_x)), scale(aperture * ort_sinf(rad), cam_y)),
-                                scale(0.1f, cam_z));
-                    dir = normalize(sub(focal, ap));
-                    wo = neg(normalize(dir));
-                    org = ap;
-                    weight = mk(1, 1, 1);
-                    primary = true;
-                    tracing = true;
-                    ORT_STAMP(tp1);
-                    ORT_STAMP_ACC(st_primary, tp0, tp1);
-                    break;
-                }
-            }
-            if (tracing) {
-                /* raycast_top_most_node (ray.cpp:1165-1176): start at the root */
-                ps = PS_HIT;
-                cur = 0;
-                sp = 0;
-                best_t = 3.402823466e+38f; /* Flt_Max, ray.cpp:627 */
-                hit_n = mk(0, 0, 0);
-                hit_prim = kNoPrim;
-                phantom_t = __builtin_inff(); /* none yet; compared with <= against best_t (<= FLT_MAX) */
-                inv_d = mk(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z); /* ray.cpp:210, once per ray */
-                if (COUNTERS) c_rays++;
+            const float4 *np = sv.nodes + 4u * (cur & NODE_INDEX_MASK);
+            float4 a = np[0], b = np[1], cc = np[2], d = np[3];
+            uint32_t c0 = om_f32_bits(d.x), c1 = om_f32_bits(d.y);
+            if (COUNTERS) c.nodes += 2;
+            /* child 0: lo = a.xyz, hi = (a.w, b.x, b.y); child 1: lo = (b.z, b.w, cc.x), hi = cc.yzw */
+            float t0x = (a.x - org.x) * inv_d.x, t1x = (a.w - org.x) * inv_d.x;
+            float t0y = (a.y - org.y) * inv_d.y, t1y = (b.x - org.y) * inv_d.y;
+            float t0z = (a.z - org.z) * inv_d.z, t1z = (b.y - org.z) * inv_d.z;
+            float n0 = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
+            float f0 = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
+            float u0x = (b.z - org.x) * inv_d.x, u1x = (cc.y - org.x) * inv_d.x;
+            float u0y = (b.w - org.y) * inv_d.y, u1y = (cc.z - org.y) * inv_d.y;
+            float u0z = (cc.x - org.z) * inv_d.z, u1z = (cc.w - org.z) * inv_d.z;
+            float n1 = fmaxf(fmaxf(fminf(u0x, u1x), fminf(u0y, u1y)), fminf(u0z, u1z));
+            float f1 = fminf(fminf(fmaxf(u0x, u1x), fmaxf(u0y, u1y)), fmaxf(u0z, u1z));
+            /* children with a sphere below are not culled by distance (phantom tangent hits) */
+            bool h0 = (f0 * 1.0000004f >= n0) && (f0 >= 0.0f) && ((n0 * 0.9999996f < h.best_t) || (c0 & SPHERE_BELOW_BIT));
+            bool h1 = (f1 * 1.0000004f >= n1) && (f1 >= 0.0f) && ((n1 * 0.9999996f < h.best_t) || (c1 & SPHERE_BELOW_BIT)) && (c1 != EMPTY_CHILD);
+            if (h0 && h1) {
+                bool swap = n1 < n0;
+                uint32_t farc = swap ? c0 : c1;
+                cur = swap ? c1 : c0;
+                if (sp < LDS_ENTRIES) lds_stack[sp * BLOCK + tid] = farc;
+                else spill[sp - LDS_ENTRIES] = farc;
+                sp++;
+            } else if (h0) {
+                cur = c0;
+            } else if (h1) {
+                cur = c1;
+            } else if (sp == 0) {
+                cur = kTraversalDone;
+            } else {
+                sp--;
+                cur = (sp < LDS_ENTRIES) ? lds_stack[sp * BLOCK + tid] : spill[sp - LDS_ENTRIES];
             }
         }
-        if (ORT_BALLOT(ps != PS_DONE) == 0ull) break;
-        ORT_STAMP(ts1);
-        ORT_STAMP_ACC(st_shade, ts0, ts1);
-
-        /* ---------------- closest hit: interruptible ordered DFS ----------------
-         * while-while: every lane first descends interior nodes until it holds a leaf (or runs
-         * out of stack), then the wave processes leaves together, so the cheap box code and the
-         * expensive primitive code are not serialised against each other in every iteration.
-         * Slab test: the reference's own (p - o) * (1/d) form (ray.cpp:215-222) with ulp margins,
-         * conservative; fminf/fmaxf drop the NaN of 0 * inf, i.e. that axis is ignored. */
-        while (tracing) {
-            ORT_STAMP(td0);
 #if ORT_TRAV_WHILEWHILE
-            while (!(cur & LEAF_BIT)) {
+        if (cur == kTraversalDone) {
 #else
-            if (!(cur & LEAF_BIT)) {
+        else if (cur == kTraversalDone) {
 #endif
-                const float4 *np = sv.nodes + 4u * (cur & NODE_INDEX_MASK);
-                float4 a = np[0], b = np[1], c = np[2], d = np[3];
-                uint32_t c0 = om_f32_bits(d.x), c1 = om_f32_bits(d.y);
-                if (COUNTERS) c_nodes += 2;
-                /* the reference's own (p - o) * 1/d form (ray.cpp:215-222) with ulp margins */
-                float t0x = (a.x - org.x) * inv_d.x, t1x = (a.w - org.x) * inv_d.x;
-                float t0y = (a.y - org.y) * inv_d.y, t1y = (b.x - org.y) * inv_d.y;
-                float t0z = (a.z - org.z) * inv_d.z, t1z = (b.y - org.z) * inv_d.z;
-                float n0 = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
-                float f0 = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
-                float u0x = (b.z - org.x) * inv_d.x, u1x = (c.y - org.x) * inv_d.x;
-                float u0y = (b.w - org.y) * inv_d.y, u1y = (c.z - org.y) * inv_d.y;
-                float u0z = (c.x - org.z) * inv_d.z, u1z = (c.w - org.z) * inv_d.z;
-                float n1 = fmaxf(fmaxf(fminf(u0x, u1x), fminf(u0y, u1y)), fminf(u0z, u1z));
-                float f1 = fminf(fminf(fmaxf(u0x, u1x), fmaxf(u0y, u1y)), fmaxf(u0z, u1z));
-                bool h0 = (f0 * 1.0000004f >= n0) && (f0 >= 0.0f) && ((n0 * 0.9999996f < best_t) || (c0 & SPHERE_BELOW_BIT));
-                bool h1 = (f1 * 1.0000004f >= n1) && (f1 >= 0.0f) && ((n1 * 0.9999996f < best_t) || (c1 & SPHERE_BELOW_BIT)) && (c1 != EMPTY_CHILD);
-                if (h0 && h1) {
-                    bool swap = n1 < n0;
-                    uint32_t farc = swap ? c0 : c1;
-                    cur = swap ? c1 : c0;
-                    if (sp < kLdsStack) lds_stack[sp * kBlock + tid] = farc;
-                    else spill[sp - kLdsStack] = farc;
-                    sp++;
-                } else if (h0) {
-                    cur = c0;
-                } else if (h1) {
-                    cur = c1;
-                } else if (sp == 0) {
-                    cur = kTraversalDone;
-                } else {
-                    sp--;
-                    cur = (sp < kLdsStack) ? lds_stack[sp * kBlock + tid] : spill[sp - kLdsStack];
-                }
-            }
-            ORT_STAMP(td1);
-            ORT_STAMP_ACC(st_descend, td0, td1);
-#if ORT_TRAV_WHILEWHILE
-            if (cur == kTraversalDone) {
-#else
-            else if (cur == kTraversalDone) {
-#endif
+            tracing = false;
+        } else {
+            uint32_t kind = (cur >> 28) & 7u, count = ((cur >> 24) & 15u) + 1u, first = cur & 0x00ffffffu;
+            for (uint32_t i = 0; i < count; ++i)
+                test_prim<COUNTERS, false>(sv, kind, first + i, org, dir, inv_d, h.best_t, h.hit_n, h.hit_prim, h.phantom_t, c.tris, c.analytic);
+            if (sp == 0) {
+                cur = kTraversalDone;
                 tracing = false;
             } else {
-                uint32_t kind = (cur >> 28) & 7u, count = ((cur >> 24) & 15u) + 1u, first = cur & 0x00ffffffu;
-                for (uint32_t i = 0; i < count; ++i)
-                    test_prim<COUNTERS, false>(sv, kind, first + i, org, dir, inv_d, best_t, hit_n, hit_prim, phantom_t, c_tris, c_analytic);
-                if (sp == 0) {
-                    cur = kTraversalDone;
-                    tracing = false;
-                } else {
-                    sp--;
-                    cur = (sp < kLdsStack) ? lds_stack[sp * kBlock + tid] : spill[sp - kLdsStack];
-                }
+                sp--;
+                cur = (sp < LDS_ENTRIES) ? lds_stack[sp * BLOCK + tid] : spill[sp - LDS_ENTRIES];
             }
-            ORT_STAMP(td2);
-            ORT_STAMP_ACC(st_leaf, td1, td2);
-            /* when most of the wave has finished its ray, let the finished lanes shade and refill */
-            if (ORT_POPC64(ORT_BALLOT(tracing)) < rv.refill_below) break;
         }
+        /* when most of the wave has finished its ray, let the finished lanes shade and refill */
+        if (refill_below > 0 && ORT_POPC64(ORT_BALLOT(tracing)) < refill_below) break;
     }
+    T.cur = cur;
+    T.sp = sp;
+    return tracing;
+}
 
-    if (COUNTERS) {
-        ORT_COUNT(rv.counters + 0, c_paths);
-        ORT_COUNT(rv.counters + 1, c_rays);
-        ORT_COUNT(rv.counters + 2, c_nodes);
-        ORT_COUNT(rv.counters + 3, c_tris);
-        ORT_COUNT(rv.counters + 4, c_analytic);
+ORT_D void flush_counters(const RenderView &rv, const Counters &c, bool all) {
+    if (all) {
+        ORT_COUNT(rv.counters + 0, c.paths);
+        ORT_COUNT(rv.counters + 1, c.rays);
+        ORT_COUNT(rv.counters + 2, c.nodes);
+        ORT_COUNT(rv.counters + 3, c.tris);
+        ORT_COUNT(rv.counters + 4, c.analytic);
     }
-#if defined(ORT_STAMPS) && !defined(ORT_HOST_SIM)
-    if ((tid & 63) == 0) {
-        atomicAdd(rv.counters + 8, st_shade);
-        atomicAdd(rv.counters + 9, st_descend);
-        atomicAdd(rv.counters + 10, st_leaf);
-        atomicAdd(rv.counters + 11, __builtin_amdgcn_s_memtime() - st_total0);
-        atomicAdd(rv.counters + 12, st_chain);
-        atomicAdd(rv.counters + 13, st_bsdf);
-        atomicAdd(rv.counters + 14, st_sample);
-        atomicAdd(rv.counters + 15, st_primary);
-        atomicAdd(rv.counters + 16, st_job);
-        atomicAdd(rv.counters + 17, st_pixend);
+    if (c.fallback) ORT_COUNT(rv.counters + 5, c.fallback);
+    if (c.overflow) ORT_COUNT(rv.counters + 6, 1ull);
+}
+
+/* persistent mode: one lane runs jobs until the job space is empty */
+template <bool COUNTERS>
+ORT_D void pt_lane(const SceneView &sv, const RenderView &rv, uint32_t *lds_stack, const int tid, const uint32_t lane_id) {
+    uint32_t spill[kSpillStack];
+    PathState P;
+    HitState h;
+    Trav T;
+    Counters c;
+    bool tracing = false;
+    for (;;) {
+        if (!tracing) {
+            if (P.ps == PS_HIT) resolve_hit<COUNTERS>(sv, P.org, P.dir, T.inv_d, lane_id, h, c);
+            tracing = produce_ray<COUNTERS>(sv, rv, P, h, c);
+            if (tracing) {
+                begin_ray(P, T, h);
+                if (COUNTERS) c.rays++;
+            }
+        }
+        if (ORT_BALLOT(P.ps != PS_DONE) == 0ull) break;
+        if (tracing) tracing = traverse<COUNTERS, kLdsStack, kBlock>(sv, P.org, P.dir, T, h, lds_stack, spill, tid, rv.refill_below, c);
     }
-#endif
-    if (c_fallback) ORT_COUNT(rv.counters + 5, c_fallback);
-    if (overflow) ORT_COUNT(rv.counters + 6, 1ull);
+    flush_counters(rv, c, COUNTERS);
+}
+
+/* ---- wavefront mode -------------------------------------------------------------------------- */
+constexpr uint32_t WF_PRIMARY = 8u, WF_HAS_RAY = 16u;
+constexpr int kWfLdsStack = 16; /* trace kernel: 16 LDS entries per lane (16 KB per 256-lane block), tail in scratch */
+constexpr int kWfSpill = 48;
+
+/* one slot: resume its path, produce the next ray, store everything back; returns true if a ray was produced */
+template <bool COUNTERS>
+ORT_D bool wf_shade_slot(const SceneView &sv, const RenderView &rv, const WfView &wf, uint32_t i, Counters &c) {
+    uint32_t fl = wf.flags[i];
+    PathState P;
+    P.ps = (int)(fl & 7u);
+    if (P.ps == PS_DONE) return false;
+    HitState h;
+    if (P.ps != PS_NEED_JOB) {
+        float4 a = wf.od0[i];
+        float2 b = wf.od1[i];
+        float4 q0 = wf.p0[i], q1 = wf.p1[i], q2 = wf.p2[i];
+        uint4 q3 = wf.p3[i];
+        float4 hh = wf.hit0[i];
+        P.org = mk(a.x, a.y, a.z); P.dir = mk(a.w, b.x, b.y);
+        P.weight = mk(q0.x, q0.y, q0.z); P.color = mk(q0.w, q1.x, q1.y); P.wo = mk(q1.z, q1.w, q2.x);
+        P.rng = om_f32_bits(q2.y); P.sample = om_f32_bits(q2.z); P.spp = om_f32_bits(q2.w);
+        P.job_index = q3.x; P.px = (int)(q3.y & 0xffffu); P.py = (int)(q3.y >> 16);
+        P.jx0 = (int)(q3.z & 0xffffu); P.jx1 = (int)(q3.z >> 16); P.jy1 = (int)(q3.w & 0xffffu); P.plane = q3.w >> 16;
+        P.primary = (fl & WF_PRIMARY) != 0;
+        h.best_t = hh.x; h.hit_n = mk(hh.y, hh.z, hh.w); h.hit_prim = wf.hitp[i];
+    }
+    bool tracing = produce_ray<COUNTERS>(sv, rv, P, h, c);
+    if (tracing) {
+        wf.od0[i] = make_float4(P.org.x, P.org.y, P.org.z, P.dir.x);
+        wf.od1[i] = make_float2(P.dir.y, P.dir.z);
+        wf.p0[i] = make_float4(P.weight.x, P.weight.y, P.weight.z, P.color.x);
+        wf.p1[i] = make_float4(P.color.y, P.color.z, P.wo.x, P.wo.y);
+        wf.p2[i] = make_float4(P.wo.z, om_bits_f32(P.rng), om_bits_f32(P.sample), om_bits_f32(P.spp));
+        wf.p3[i] = make_uint4(P.job_index, (uint32_t)P.px | ((uint32_t)P.py << 16), (uint32_t)P.jx0 | ((uint32_t)P.jx1 << 16),
+                              (uint32_t)P.jy1 | (P.plane << 16));
+        if (COUNTERS) c.rays++;
+    }
+    wf.flags[i] = (uint32_t)P.ps | (P.primary ? WF_PRIMARY : 0u) | (tracing ? WF_HAS_RAY : 0u);
+    return tracing;
+}
+
+/* one slot: closest hit of its ray, resolved to the reference's answer */
+template <bool COUNTERS>
+ORT_D void wf_trace_slot(const SceneView &sv, const WfView &wf, uint32_t i, uint32_t lane_id, uint32_t *lds_stack, uint32_t *spill,
+                         int tid, Counters &c) {
+    if (!(wf.flags[i] & WF_HAS_RAY)) return;
+    float4 a = wf.od0[i];
+    float2 b = wf.od1[i];
+    PathState P;
+    P.org = mk(a.x, a.y, a.z); P.dir = mk(a.w, b.x, b.y);
+    HitState h;
+    Trav T;
+    begin_ray(P, T, h);
+    traverse<COUNTERS, kWfLdsStack, kBlock>(sv, P.org, P.dir, T, h, lds_stack, spill, tid, 0, c);
+    resolve_hit<COUNTERS>(sv, P.org, P.dir, T.inv_d, lane_id, h, c);
+    wf.hit0[i] = make_float4(h.best_t, h.hit_n.x, h.hit_n.y, h.hit_n.z);
+    wf.hitp[i] = h.hit_prim;
 }
 
 /* pixel = (sum over k of partial[k], in k order) / nchunks for one pixel (CHUNK policy) */
@@ -617,6 +702,37 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(ORT
 pt_persistent(SceneView sv, RenderView rv) {
     __shared__ uint32_t lds_stack[kLdsStack * kBlock];
     pt_lane<COUNTERS>(sv, rv, lds_stack, (int)threadIdx.x, blockIdx.x * (uint32_t)kBlock + threadIdx.x);
+}
+
+/* wavefront kernels: fixed-size grids, grid-stride over the slots (so a lane id < grid size indexes
+   the fallback rings) */
+template <bool COUNTERS>
+__global__ void __launch_bounds__(kBlock) wf_shade(SceneView sv, RenderView rv, WfView wf, int count_active) {
+    Counters c;
+    unsigned long long produced = 0;
+    const uint32_t stride = gridDim.x * (uint32_t)kBlock;
+    for (uint32_t i = blockIdx.x * (uint32_t)kBlock + threadIdx.x; i < wf.slots; i += stride)
+        if (wf_shade_slot<COUNTERS>(sv, rv, wf, i, c)) produced++;
+    if (count_active && produced) atomicAdd(wf.active, produced);
+    flush_counters(rv, c, COUNTERS);
+}
+
+template <bool COUNTERS>
+__global__ void __launch_bounds__(kBlock) wf_trace(SceneView sv, RenderView rv, WfView wf) {
+    __shared__ uint32_t lds_stack[kWfLdsStack * kBlock];
+    uint32_t spill[kWfSpill];
+    Counters c;
+    const uint32_t stride = gridDim.x * (uint32_t)kBlock;
+    const uint32_t lane_id = blockIdx.x * (uint32_t)kBlock + threadIdx.x;
+    for (uint32_t i = lane_id; i < wf.slots; i += stride)
+        wf_trace_slot<COUNTERS>(sv, wf, i, lane_id, lds_stack, spill, (int)threadIdx.x, c);
+    flush_counters(rv, c, COUNTERS);
+}
+
+__global__ void wf_init(WfView wf) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < wf.slots) wf.flags[i] = (uint32_t)PS_NEED_JOB;
+    if (i == 0) *wf.active = 0ull;
 }
 
 /* per-function evaluation on the device, for the parity tests: records of {u32 op; f32 in[24]}
@@ -731,6 +847,8 @@ void device_release(Scene *scene) {
                     d->box_chain, d->cyl_chain, d->tri_order, d->sphere_order, d->box_order, d->cyl_order, d->bfs_queue, d->ctrl, d->partial, d->staging, d->jobs, d->states};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    if (d->wf_mem) (void)hipFree(d->wf_mem);
+    if (d->h_active) (void)hipHostFree(d->h_active);
     if (d->ev0) (void)hipEventDestroy(d->ev0);
     if (d->ev1) (void)hipEventDestroy(d->ev1);
     delete d;
@@ -777,8 +895,8 @@ int device_upload(Scene *scene, int device, std::string *err) {
     if ((rc = upload_vec(rt.sphere_order, &d->sphere_order, err))) return rc;
     if ((rc = upload_vec(rt.box_order, &d->box_order, err))) return rc;
     if ((rc = upload_vec(rt.cyl_order, &d->cyl_order, err))) return rc;
-    ORT_HIP(hipMalloc((void **)&d->ctrl, 24 * sizeof(unsigned long long)));
-    ORT_HIP(hipMemset(d->ctrl, 0, 24 * sizeof(unsigned long long)));
+    ORT_HIP(hipMalloc((void **)&d->ctrl, 8 * sizeof(unsigned long long)));
+    ORT_HIP(hipMemset(d->ctrl, 0, 8 * sizeof(unsigned long long)));
     ORT_HIP(hipEventCreate(&d->ev0));
     ORT_HIP(hipEventCreate(&d->ev1));
     hipDeviceProp_t prop;
@@ -786,7 +904,9 @@ int device_upload(Scene *scene, int device, std::string *err) {
     d->cu_count = prop.multiProcessorCount;
     /* persistent grid: 4 workgroups of 256 lanes per CU; one fallback ring per lane (8 KB, 2 GB total) */
     d->max_blocks = (unsigned int)(d->cu_count > 0 ? d->cu_count : 256) * 4u;
-    ORT_HIP(hipMalloc(&d->bfs_queue, (size_t)d->max_blocks * kBlock * kBfsQueue * sizeof(uint32_t)));
+    /* one fallback ring per resident lane of the widest grid (wavefront trace: 8 workgroups per CU); 4 GB */
+    ORT_HIP(hipMalloc(&d->bfs_queue, (size_t)d->max_blocks * 2u * kBlock * kBfsQueue * sizeof(uint32_t)));
+    ORT_HIP(hipHostMalloc((void **)&d->h_active, sizeof(unsigned long long)));
     return ORT_OK;
 }
 
@@ -821,6 +941,51 @@ static int ensure(void **ptr, size_t *have, size_t need, std::string *err) {
     *have = 0;
     ORT_HIP(hipMalloc(ptr, need ? need : 16));
     *have = need;
+    return ORT_OK;
+}
+
+/* wavefront mode: all slots alternate between wf_shade (produce the next ray) and wf_trace (closest
+   hit) until no slot produces a ray any more.  The host only learns "finished" by reading a
+   counter, so it launches iterations in batches and checks after each batch. */
+template <bool COUNTERS>
+static int launch_wavefront(DeviceScene *d, const SceneView &sv, const RenderView &rv, hipStream_t stream, std::string *err) {
+    const uint32_t kMaxSlots = 1u << 21;
+    unsigned long long want = rv.job_count < kMaxSlots ? rv.job_count : kMaxSlots;
+    uint32_t S = (uint32_t)((want + kBlock - 1) / kBlock) * kBlock;
+    if (S == 0) S = kBlock;
+    const size_t per_slot = 16 + 8 + 16 + 4 + 16 + 16 + 16 + 16 + 4;
+    size_t need = (size_t)S * per_slot + 4096;
+    int rc = ensure(&d->wf_mem, &d->wf_bytes, need, err);
+    if (rc) return rc;
+    WfView wf{};
+    wf.slots = S;
+    char *base = (char *)d->wf_mem;
+    auto carve = [&](size_t bytes) { char *p = base; base += (bytes + 255) & ~(size_t)255; return p; };
+    wf.active = (unsigned long long *)carve(256);
+    wf.od0 = (float4 *)carve((size_t)S * 16); wf.hit0 = (float4 *)carve((size_t)S * 16);
+    wf.p0 = (float4 *)carve((size_t)S * 16); wf.p1 = (float4 *)carve((size_t)S * 16); wf.p2 = (float4 *)carve((size_t)S * 16);
+    wf.p3 = (uint4 *)carve((size_t)S * 16);
+    wf.od1 = (float2 *)carve((size_t)S * 8);
+    wf.hitp = (uint32_t *)carve((size_t)S * 4); wf.flags = (uint32_t *)carve((size_t)S * 4);
+    if ((size_t)(base - (char *)d->wf_mem) > d->wf_bytes) { *err = "internal: wavefront state carve overflow"; return ORT_ERR_INVALID; }
+
+    unsigned int blocks = S / kBlock;
+    unsigned int grid = blocks < d->max_blocks * 2u ? blocks : d->max_blocks * 2u;
+    hipLaunchKernelGGL(wf_init, dim3(blocks), dim3(kBlock), 0, stream, wf);
+    ORT_HIP(hipGetLastError());
+    const int batch = 32;
+    for (;;) {
+        for (int it = 0; it < batch; ++it) {
+            int last = (it == batch - 1);
+            if (last) ORT_HIP(hipMemsetAsync(wf.active, 0, sizeof(unsigned long long), stream));
+            hipLaunchKernelGGL(wf_shade<COUNTERS>, dim3(grid), dim3(kBlock), 0, stream, sv, rv, wf, last);
+            hipLaunchKernelGGL(wf_trace<COUNTERS>, dim3(grid), dim3(kBlock), 0, stream, sv, rv, wf);
+        }
+        ORT_HIP(hipGetLastError());
+        ORT_HIP(hipMemcpyAsync(d->h_active, wf.active, sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+        ORT_HIP(hipStreamSynchronize(stream));
+        if (*d->h_active == 0ull) break;
+    }
     return ORT_OK;
 }
 
@@ -902,7 +1067,7 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
     }
 
     const bool counters = (p->flags & ORT_RENDER_COUNTERS) != 0;
-    ORT_HIP(hipMemsetAsync(d->ctrl, 0, 24 * sizeof(unsigned long long), stream));
+    ORT_HIP(hipMemsetAsync(d->ctrl, 0, 8 * sizeof(unsigned long long), stream));
     /* persistent grid: 4 blocks of 256 lanes per CU, never more lanes than jobs */
     unsigned long long lanes_wanted = rv.job_count;
     unsigned int max_blocks = d->max_blocks;
@@ -910,9 +1075,16 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
     if (grid > max_blocks) grid = max_blocks;
     if (grid == 0) grid = 1;
     if (stats) ORT_HIP(hipEventRecord(d->ev0, stream));
-    if (counters) hipLaunchKernelGGL(pt_persistent<true>, dim3(grid), dim3(kBlock), 0, stream, sv, rv);
-    else hipLaunchKernelGGL(pt_persistent<false>, dim3(grid), dim3(kBlock), 0, stream, sv, rv);
-    ORT_HIP(hipGetLastError());
+    const char *mode_env = getenv("ORT_MODE"); /* "wavefront" | "persistent"; results are identical */
+    const bool wavefront = mode_env ? (strcmp(mode_env, "wavefront") == 0) : false;
+    if (wavefront) {
+        rc = counters ? launch_wavefront<true>(d, sv, rv, stream, err) : launch_wavefront<false>(d, sv, rv, stream, err);
+        if (rc) return rc;
+    } else {
+        if (counters) hipLaunchKernelGGL(pt_persistent<true>, dim3(grid), dim3(kBlock), 0, stream, sv, rv);
+        else hipLaunchKernelGGL(pt_persistent<false>, dim3(grid), dim3(kBlock), 0, stream, sv, rv);
+        ORT_HIP(hipGetLastError());
+    }
     if (rv.mode == JOBS_CHUNK) {
         unsigned long long total = (unsigned long long)rv.my_blocks * 64ull;
         unsigned int cgrid = (unsigned int)((total + 255) / 256);
@@ -936,16 +1108,6 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
         float ms = 0;
         ORT_HIP(hipEventElapsedTime(&ms, d->ev0, d->ev1));
         stats->kernel_ms = ms;
-#ifdef ORT_STAMPS
-        {
-            unsigned long long c[10];
-            ORT_HIP(hipMemcpy(c, d->ctrl + 9, sizeof(c), hipMemcpyDeviceToHost));
-            fprintf(stderr, "[stamps] job %.3f pixend %.3f\n", (double)c[8] / c[3], (double)c[9] / c[3]);
-            fprintf(stderr, "[stamps] shade %.3f (chain %.3f bsdf %.3f sample %.3f primary %.3f) descend %.3f leaf %.3f of wave time (%llu Mcycles)\n",
-                    (double)c[0] / c[3], (double)c[4] / c[3], (double)c[5] / c[3], (double)c[6] / c[3], (double)c[7] / c[3],
-                    (double)c[1] / c[3], (double)c[2] / c[3], c[3] / 1000000ull);
-        }
-#endif
         if (counters) {
             unsigned long long c[6];
             ORT_HIP(hipMemcpy(c, d->ctrl + 1, sizeof(c), hipMemcpyDeviceToHost));

@@ -144,6 +144,26 @@ def test_pixel_policy_is_chunk_with_one_chunk(api, gpu_scene):
     assert_bits_equal(a, b)
 
 
+def test_wavefront_mode_equals_persistent_mode(api, gpu_scene, monkeypatch):
+    """the two execution modes (one persistent kernel / HBM-resident wavefront) run the same lane code"""
+    scene = gpu_scene("c4_dwarf_room")
+    monkeypatch.setenv("ORT_MODE", "persistent")
+    a, _ = scene.render(100, 60, 8, 3, "chunk", chunk=4)
+    monkeypatch.setenv("ORT_MODE", "wavefront")
+    b, st = scene.render(100, 60, 8, 3, "chunk", chunk=4, counters=True)
+    assert st["paths"] == 100 * 60 * 8
+    assert_bits_equal(a, b)
+    out = np.zeros((24, 32, 3), "<f4")
+    ref = np.zeros((24, 32, 3), "<f4")
+    jobs = np.zeros(3, api.JOB_DTYPE)
+    jobs[0] = (0, 0, 8, 8, 11, 2); jobs[1] = (8, 0, 32, 3, 12, 1); jobs[2] = (31, 23, 32, 24, 5, 7)
+    fw, _ = scene.tiled_raytrace_batch(out, jobs)
+    monkeypatch.setenv("ORT_MODE", "persistent")
+    fp, _ = scene.tiled_raytrace_batch(ref, jobs)
+    assert (fw == fp).all()
+    assert_bits_equal(out, ref)
+
+
 def test_determinism(api, gpu_scene):
     scene = gpu_scene("testscene")
     a, _ = scene.render(128, 72, 8, 1, "chunk", chunk=4)

@@ -99,6 +99,26 @@ int main(int argc, char **argv) {
     auto t0 = std::chrono::steady_clock::now();
     std::vector<uint32_t> bfsq(kBfsQueue);
     sv.bfs_queue = bfsq.data();
+    if (getenv("SIM_WAVEFRONT")) {
+        /* the wavefront schedule with a small slot pool: shade all slots, trace all slots, repeat */
+        uint32_t S = (uint32_t)atoi(getenv("SIM_WAVEFRONT"));
+        if (S > rv.job_count) S = (uint32_t)rv.job_count;
+        std::vector<float4> od0(S), hit0(S), p0(S), p1(S), p2(S);
+        std::vector<float2> od1(S);
+        std::vector<uint4> p3(S);
+        std::vector<uint32_t> hitp(S), flags(S, (uint32_t)PS_NEED_JOB);
+        unsigned long long active = 0;
+        WfView wf{S, od0.data(), od1.data(), hit0.data(), hitp.data(), p0.data(), p1.data(), p2.data(), p3.data(), flags.data(), &active};
+        std::vector<uint32_t> wlds(kWfLdsStack * kBlock), wspill(kWfSpill);
+        Counters c;
+        for (;;) {
+            unsigned long long produced = 0;
+            for (uint32_t i = 0; i < S; ++i) produced += wf_shade_slot<true>(sv, rv, wf, i, c) ? 1 : 0;
+            if (!produced) break;
+            for (uint32_t i = 0; i < S; ++i) wf_trace_slot<true>(sv, wf, i, 0, wlds.data(), wspill.data(), 0, c);
+        }
+        flush_counters(rv, c, true);
+    } else
     pt_lane<true>(sv, rv, lds.data(), 0, 0);
     if (rv.mode == JOBS_CHUNK)
         for (unsigned long long i = 0; i < (unsigned long long)rv.my_blocks * 64; ++i) combine_pixel(rv, i);
