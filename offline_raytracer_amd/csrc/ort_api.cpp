@@ -36,6 +36,8 @@ int check_params(const ort_scene *scene, const ort_render_params *p) {
     if (!scene || !p) return fail(ORT_ERR_INVALID, "null scene or params");
     if (p->width <= 0 || p->height <= 0) return fail(ORT_ERR_INVALID, "image size must be positive");
     if ((uint64_t)p->width * (uint64_t)p->height > 0x7fffffffull / 3) return fail(ORT_ERR_INVALID, "image too large");
+    if (p->width > 65535 || p->height > 65535) return fail(ORT_ERR_UNSUPPORTED, "image side above 65535 (lane state packs coordinates in 16 bits)");
+    if (p->policy == ORT_POLICY_CHUNK && p->chunk && p->spp / p->chunk > 65535u) return fail(ORT_ERR_UNSUPPORTED, "more than 65535 chunks");
     if (p->x0 < 0 || p->y0 < 0 || p->x1 > p->width || p->y1 > p->height || p->x0 >= p->x1 || p->y0 >= p->y1)
         return fail(ORT_ERR_INVALID, "render rect is empty or outside the image");
     if (p->spp == 0) return fail(ORT_ERR_INVALID, "spp must be >= 1");

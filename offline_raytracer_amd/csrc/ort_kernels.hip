@@ -55,6 +55,7 @@ struct SceneView {
     const uint32_t *tri_chain, *sphere_chain, *box_chain, *cyl_chain;
     const uint32_t *tri_order, *sphere_order, *box_order, *cyl_order; /* reference test order (ties) */
     uint32_t *bfs_queue;       /* kBfsQueue entries per lane: ring buffer of the exact fallback */
+    unsigned long long *fallback_counters; /* [0] rays re-cast exactly, [1] ring overflows */
 };
 
 enum : int { JOBS_EXPLICIT = 0, JOBS_PIXEL = 1, JOBS_CHUNK = 2 };
@@ -292,16 +293,18 @@ ORT_D bool ref_raycast_bfs(const SceneView &sv, V3 org, V3 dir, V3 inv_d, uint32
  *   wavefront : path state lives in HBM; wf_shade runs produce_ray once per slot, wf_trace
  *               runs traverse + resolve_hit once per slot, alternating over all slots. */
 struct Counters {
-    unsigned long long paths = 0, rays = 0, nodes = 0, tris = 0, analytic = 0, fallback = 0;
-    bool overflow = false;
+    unsigned long long paths = 0, rays = 0, nodes = 0, tris = 0, analytic = 0;
 };
 
+/* job bookkeeping is packed (image sizes and chunk counts fit 16 bits; checked on the host) so that
+   few registers stay live across the traversal loop */
 struct PathState {
     int ps = PS_NEED_JOB;
     uint32_t rng = 0, job_index = 0;
-    int jx0 = 0, jx1 = 0, jy1 = 0, px = 0, py = 0;
+    uint32_t pxy = 0;  /* px | py << 16: the pixel being rendered */
+    uint32_t jxx = 0;  /* jx0 | jx1 << 16: the job rect's x range */
+    uint32_t jyp = 0;  /* jy1 | plane << 16: the rect's end row; CHUNK policy: which partial plane */
     uint32_t spp = 0, sample = 0;
-    uint32_t plane = 0; /* CHUNK policy: which partial plane this job writes */
     V3 color, org, dir, wo, weight;
     bool primary = true;
 };
@@ -322,10 +325,10 @@ ORT_D float *job_plane(const RenderView &rv, uint32_t plane) {
 template <bool COUNTERS>
 ORT_D void resolve_hit(const SceneView &sv, V3 org, V3 dir, V3 inv_d, uint32_t lane_id, HitState &h, Counters &c) {
     if ((h.hit_prim != kNoPrim && !chain_admits(sv, h.hit_prim, org, inv_d)) || h.phantom_t <= h.best_t) {
-        c.fallback++;
+        ORT_COUNT(sv.fallback_counters, 1ull); /* rare: straight to memory, no register kept across the loop */
         if (!ref_raycast_bfs<COUNTERS>(sv, org, dir, inv_d, sv.bfs_queue + (size_t)lane_id * kBfsQueue, h.best_t, h.hit_n, h.hit_prim,
                                        c.nodes, c.tris, c.analytic))
-            c.overflow = true;
+            ORT_COUNT(sv.fallback_counters + 1, 1ull);
     }
 }
 
@@ -348,10 +351,10 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderView &rv, PathState &P, 
             if (rv.mode == JOBS_EXPLICIT) {
                 ort_tile_job jb = rv.jobs[j];
                 P.job_index = (uint32_t)j;
-                P.jx0 = jb.x0; P.jx1 = jb.x1; P.jy1 = jb.y1;
-                P.px = jb.x0; P.py = jb.y0;
+                P.jxx = (uint32_t)jb.x0 | ((uint32_t)jb.x1 << 16);
+                P.jyp = (uint32_t)jb.y1;
+                P.pxy = (uint32_t)jb.x0 | ((uint32_t)jb.y0 << 16);
                 P.rng = jb.rng_state; P.spp = jb.spp;
-                P.plane = 0;
                 if (jb.x1 <= jb.x0 || jb.y1 <= jb.y0) { /* empty rect: the reference loops zero times */
                     if (rv.final_states) rv.final_states[P.job_index] = P.rng;
                     continue;
@@ -367,21 +370,22 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderView &rv, PathState &P, 
                 int y = (int)((blk / rv.blocks_w) * 8u + (pin >> 3));
                 if (x < rv.x0 || x >= rv.x1 || y < rv.y0 || y >= rv.y1) continue;
                 uint32_t pix = (uint32_t)(y * rv.W + x);
-                P.jx0 = x; P.jx1 = x + 1; P.jy1 = y + 1; P.px = x; P.py = y;
+                P.jxx = (uint32_t)x | ((uint32_t)(x + 1) << 16);
+                P.pxy = (uint32_t)x | ((uint32_t)y << 16);
                 if (rv.mode == JOBS_PIXEL) {
                     P.rng = job_seed(rv.seed, pix);
                     P.spp = rv.spp;
-                    P.plane = 0;
+                    P.jyp = (uint32_t)(y + 1);
                 } else {
                     P.rng = job_seed(rv.seed, k * (uint32_t)(rv.W * rv.H) + pix);
                     P.spp = rv.chunk;
-                    P.plane = k;
+                    P.jyp = (uint32_t)(y + 1) | (k << 16);
                 }
             }
             P.ps = PS_PIXEL;
         }
         if (P.ps == PS_PIXEL) {
-            ORT_SIM_PIXEL_HOOK(P.px, P.py, P.rng);
+            ORT_SIM_PIXEL_HOOK((int)(P.pxy & 0xffffu), (int)(P.pxy >> 16), P.rng);
             P.color = mk(0, 0, 0); /* ray.cpp:1211 */
             P.sample = 0;
             P.ps = PS_SAMPLE;
@@ -396,7 +400,7 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderView &rv, PathState &P, 
                         : (hk == PRIM_BOX) ? sv.box_mat[hs] : sv.cyl_mat[hs];
             }
             V3 n = normalize(h.hit_n);
-            ORT_SIM_RAY_HOOK(P.px, P.py, P.org, P.dir, h.best_t, n, hit_mat);
+            ORT_SIM_RAY_HOOK((int)(P.pxy & 0xffffu), (int)(P.pxy >> 16), P.org, P.dir, h.best_t, n, hit_mat);
             if (COUNTERS && P.primary) c.paths++;
             Mat m;
             if (hit_mat) m = load_mat(sv.materials, hit_mat);
@@ -443,11 +447,13 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderView &rv, PathState &P, 
             if (P.sample == P.spp) {
                 /* ray.cpp:1428 */
                 V3 o = divs(P.color, (float)P.spp);
-                float *p = job_plane(rv, P.plane) + 3u * ((size_t)P.py * (size_t)rv.W + (size_t)P.px);
+                uint32_t px = P.pxy & 0xffffu, py = P.pxy >> 16;
+                float *p = job_plane(rv, P.jyp >> 16) + 3u * ((size_t)py * (size_t)rv.W + (size_t)px);
                 p[0] = o.x; p[1] = o.y; p[2] = o.z;
-                P.px++;
-                if (P.px == P.jx1) { P.px = P.jx0; P.py++; }
-                if (P.py == P.jy1) {
+                px++;
+                if (px == (P.jxx >> 16)) { px = P.jxx & 0xffffu; py++; }
+                P.pxy = px | (py << 16);
+                if (py == (P.jyp & 0xffffu)) {
                     if (rv.mode == JOBS_EXPLICIT && rv.final_states) rv.final_states[P.job_index] = P.rng;
                     P.ps = PS_NEED_JOB;
                 } else {
@@ -457,8 +463,8 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderView &rv, PathState &P, 
             }
             /* ray.cpp:1215-1221: point on the focal plane through the pixel centre (recomputed per
                sample instead of held in registers: same expressions, same bits) */
-            float fx = (2.0f * P.px / (float)rv.W) - 1.0f;
-            float fy = (2.0f * P.py / (float)rv.H) - 1.0f;
+            float fx = (2.0f * (int)(P.pxy & 0xffffu) / (float)rv.W) - 1.0f; /* i32 -> f32, as the reference's x, y */
+            float fy = (2.0f * (int)(P.pxy >> 16) / (float)rv.H) - 1.0f;
             V3 to_pixel = normalize(sub(add(scale(fx, cam_x), scale(fy, cam_y)), cam_z));
             V3 focal = add(cam_p, scale(focal_length, to_pixel));
             /* ray.cpp:1232-1246 */
@@ -586,8 +592,6 @@ ORT_D void flush_counters(const RenderView &rv, const Counters &c, bool all) {
         ORT_COUNT(rv.counters + 3, c.tris);
         ORT_COUNT(rv.counters + 4, c.analytic);
     }
-    if (c.fallback) ORT_COUNT(rv.counters + 5, c.fallback);
-    if (c.overflow) ORT_COUNT(rv.counters + 6, 1ull);
 }
 
 /* persistent mode: one lane runs jobs until the job space is empty */
@@ -636,8 +640,7 @@ ORT_D bool wf_shade_slot(const SceneView &sv, const RenderView &rv, const WfView
         P.org = mk(a.x, a.y, a.z); P.dir = mk(a.w, b.x, b.y);
         P.weight = mk(q0.x, q0.y, q0.z); P.color = mk(q0.w, q1.x, q1.y); P.wo = mk(q1.z, q1.w, q2.x);
         P.rng = om_f32_bits(q2.y); P.sample = om_f32_bits(q2.z); P.spp = om_f32_bits(q2.w);
-        P.job_index = q3.x; P.px = (int)(q3.y & 0xffffu); P.py = (int)(q3.y >> 16);
-        P.jx0 = (int)(q3.z & 0xffffu); P.jx1 = (int)(q3.z >> 16); P.jy1 = (int)(q3.w & 0xffffu); P.plane = q3.w >> 16;
+        P.job_index = q3.x; P.pxy = q3.y; P.jxx = q3.z; P.jyp = q3.w;
         P.primary = (fl & WF_PRIMARY) != 0;
         h.best_t = hh.x; h.hit_n = mk(hh.y, hh.z, hh.w); h.hit_prim = wf.hitp[i];
     }
@@ -648,8 +651,7 @@ ORT_D bool wf_shade_slot(const SceneView &sv, const RenderView &rv, const WfView
         wf.p0[i] = make_float4(P.weight.x, P.weight.y, P.weight.z, P.color.x);
         wf.p1[i] = make_float4(P.color.y, P.color.z, P.wo.x, P.wo.y);
         wf.p2[i] = make_float4(P.wo.z, om_bits_f32(P.rng), om_bits_f32(P.sample), om_bits_f32(P.spp));
-        wf.p3[i] = make_uint4(P.job_index, (uint32_t)P.px | ((uint32_t)P.py << 16), (uint32_t)P.jx0 | ((uint32_t)P.jx1 << 16),
-                              (uint32_t)P.jy1 | (P.plane << 16));
+        wf.p3[i] = make_uint4(P.job_index, P.pxy, P.jxx, P.jyp);
         if (COUNTERS) c.rays++;
     }
     wf.flags[i] = (uint32_t)P.ps | (P.primary ? WF_PRIMARY : 0u) | (tracing ? WF_HAS_RAY : 0u);
@@ -695,7 +697,7 @@ ORT_D void combine_pixel(const RenderView &rv, unsigned long long idx) {
 
 #ifndef ORT_HOST_SIM
 #ifndef ORT_WAVES_PER_EU
-#define ORT_WAVES_PER_EU 3 /* VGPR budget: 3 waves/SIMD = 168 registers (tuned on MI355X) */
+#define ORT_WAVES_PER_EU 4 /* VGPR budget: 4 waves/SIMD = 128 registers, 16 spilled (tuned on MI355X: profiles/r01_tuning.md) */
 #endif
 template <bool COUNTERS>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(ORT_WAVES_PER_EU, ORT_WAVES_PER_EU)))
@@ -1020,6 +1022,7 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
     sv.tri_order = (const uint32_t *)d->tri_order; sv.sphere_order = (const uint32_t *)d->sphere_order;
     sv.box_order = (const uint32_t *)d->box_order; sv.cyl_order = (const uint32_t *)d->cyl_order;
     sv.bfs_queue = (uint32_t *)d->bfs_queue;
+    sv.fallback_counters = d->ctrl + 6;
     ort_camera cam;
     camera_basis(*scene, p->width, p->height, &cam);
     memcpy(sv.cam, &cam, sizeof(cam));
@@ -1031,7 +1034,7 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
     rv.out = out;
     {
         const char *e = getenv("ORT_REFILL_BELOW"); /* tuning knob; results do not depend on it */
-        rv.refill_below = e ? atoi(e) : 16; /* tuned on MI355X: profiles/r01_tuning.md */
+        rv.refill_below = e ? atoi(e) : 12; /* tuned on MI355X: profiles/r01_tuning.md */
         if (rv.refill_below < 1) rv.refill_below = 1;
         if (rv.refill_below > 64) rv.refill_below = 64;
     }

@@ -66,8 +66,9 @@ int main(int argc, char **argv) {
     RenderView rv{};
     rv.W = W; rv.H = H; rv.x0 = 0; rv.y0 = 0; rv.x1 = W; rv.y1 = H;
     rv.seed = seed; rv.spp = spp; rv.chunk = chunk; rv.rr = 0.8f;
-    rv.refill_below = 16;
+    rv.refill_below = 12;
     rv.out = out.data(); rv.next_job = ctrl; rv.counters = ctrl + 1;
+    sv.fallback_counters = ctrl + 6;
     rv.shard_count = argc > 11 ? (uint32_t)atoi(argv[11]) : 1; rv.shard_index = argc > 11 ? (uint32_t)atoi(argv[10]) : 0;
     rv.blocks_w = (uint32_t)((W + 7) / 8);
     uint32_t blocks_total = rv.blocks_w * (uint32_t)((H + 7) / 8);
