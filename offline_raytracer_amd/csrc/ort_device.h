@@ -213,28 +213,42 @@ ORT_D float pdf_brdf(V3 N, V3 wi, V3 wo, float rough, const Mat &mt) {          
     return pd_c * pd + ps_c * ps + pt_c * pt;
 }
 
-ORT_D V3 sample_lobe(V3 N, float c, float phi) {                                  /* ray.cpp:1065-1091 */
-    N = normalize(N);
+/* sample_lobe (ray.cpp:1065-1091) with cos(phi), sin(phi) supplied by the caller, so that the
+   kernel can evaluate the (double-precision) sine/cosine once for lanes in different states */
+/* Nn = normalize(N) (ray.cpp:1069) is evaluated by the caller */
+ORT_D V3 sample_lobe_n(V3 N, float c, float cos_phi, float sin_phi) {
     float s = __builtin_sqrtf(1.0f - c * c);
-    V3 K = mk(s * ort_cosf(phi), s * ort_sinf(phi), c);
+    V3 K = mk(s * cos_phi, s * sin_phi, c);
     if (absr(N.z - 1.0f) < 0.0001f) return K;
     if (absr(N.z + 1.0f) < 0.0001f) return mk(K.x, -K.y, -K.z);
     V3 B = normalize(mk(-N.y, N.x, 0));
     V3 C = cross(N, B);
     return add(add(scale(K.x, B), scale(K.y, C)), scale(K.z, N));
 }
+ORT_D V3 sample_lobe(V3 N, float c, float phi) { return sample_lobe_n(normalize(N), c, ort_cosf(phi), ort_sinf(phi)); }
 
-ORT_D V3 sample_brdf(uint32_t &rng, V3 N, V3 wo, float rough, const Mat &mt, bool &is_trans) { /* ray.cpp:1100-1161 */
+/* sample_brdf (ray.cpp:1100-1161) in two halves around the evaluation of cos/sin(phi):
+   draw: the three RNG draws, the lobe's cos(theta) and the azimuth phi = 2 pi e1 */
+struct BrdfDraw { float c, phi, choice; };
+ORT_D BrdfDraw sample_brdf_draw(uint32_t &rng, float rough, const Mat &mt) {
+    float e0 = rng_01(rng), e1 = rng_01(rng);
+    BrdfDraw d;
+    d.choice = rng_01(rng);
+    d.phi = 2.0f * kPi * e1;
+    if (d.choice < mt.pd_c) d.c = __builtin_sqrtf(e0);                                                  /* ray.cpp:1123 */
+    else d.c = ort_cosf(ort_atan2f(rough * __builtin_sqrtf(e0), __builtin_sqrtf(1.0f - e0)));          /* ray.cpp:1128,1138 */
+    return d;
+}
+/* finish: the direction from the lobe sample */
+ORT_D V3 sample_brdf_finish(V3 N, V3 wo, const Mat &mt, BrdfDraw d, float cos_phi, float sin_phi, bool &is_trans) {
     float pd_c = mt.pd_c, ps_c = mt.ps_c; /* per material, ray.cpp:1105-1113 */
-    float e0 = rng_01(rng), e1 = rng_01(rng), choice = rng_01(rng);
     V3 wi;
     is_trans = false;
-    if (choice < pd_c) {
-        wi = sample_lobe(N, __builtin_sqrtf(e0), 2.0f * kPi * e1);
+    V3 m = sample_lobe_n(normalize(N), d.c, cos_phi, sin_phi); /* ray.cpp:1069 re-normalises N */
+    if (d.choice < pd_c) {
+        wi = m;
     } else {
-        float ct = ort_cosf(ort_atan2f(rough * __builtin_sqrtf(e0), __builtin_sqrtf(1.0f - e0)));
-        V3 m = sample_lobe(N, ct, 2.0f * kPi * e1);
-        bool refract = !(choice >= pd_c && choice < pd_c + ps_c);
+        bool refract = !(d.choice >= pd_c && d.choice < pd_c + ps_c);
         Beer bn;
         float r = 0.0f;
         if (refract) {
@@ -249,7 +263,11 @@ ORT_D V3 sample_brdf(uint32_t &rng, V3 N, V3 wo, float rough, const Mat &mt, boo
             is_trans = true;
         }
     }
-    return normalize(wi);
+    return normalize(wi); /* ray.cpp:1158 */
+}
+ORT_D V3 sample_brdf(uint32_t &rng, V3 N, V3 wo, float rough, const Mat &mt, bool &is_trans) {
+    BrdfDraw d = sample_brdf_draw(rng, rough, mt);
+    return sample_brdf_finish(N, wo, mt, d, ort_cosf(d.phi), ort_sinf(d.phi), is_trans);
 }
 
 /* ---- intersectors ----------------------------------------------------------------------- */

@@ -390,6 +390,11 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderView &rv, PathState &P, 
             P.sample = 0;
             P.ps = PS_SAMPLE;
         }
+        bool bounce = false;
+        float angle = 0.0f;
+        BrdfDraw draw;
+        Mat m;
+        V3 n, focal;
         if (P.ps == PS_HIT) {
             /* a traversal has finished: ray.cpp:817 then :1251-1277 (primary) or :1355-1421 (bounce) */
             bool alive = true;
@@ -399,10 +404,9 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderView &rv, PathState &P, 
                 hit_mat = (hk == PRIM_TRI) ? sv.tri_mat[hs] : (hk == PRIM_SPHERE) ? sv.sphere_mat[hs]
                         : (hk == PRIM_BOX) ? sv.box_mat[hs] : sv.cyl_mat[hs];
             }
-            V3 n = normalize(h.hit_n);
+            n = normalize(h.hit_n);
             ORT_SIM_RAY_HOOK((int)(P.pxy & 0xffffu), (int)(P.pxy >> 16), P.org, P.dir, h.best_t, n, hit_mat);
             if (COUNTERS && P.primary) c.paths++;
-            Mat m;
             if (hit_mat) m = load_mat(sv.materials, hit_mat);
             if (!hit_mat) {
                 alive = false; /* bounce miss: ray.cpp:1418-1421; primary miss: undefined in the reference, defined: terminate */
@@ -427,23 +431,22 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderView &rv, PathState &P, 
             }
             P.primary = false;
             /* ray.cpp:1280: the roulette draw happens only while the path is alive */
-            if (alive && rng_01(P.rng) < rv.rr) {
+            bounce = alive && rng_01(P.rng) < rv.rr;
+            if (bounce) {
                 /* sample_random_lights (ray.cpp:537-601): result unused, RNG advances */
                 rng_step(P.rng);
                 if (sv.light_count) {
                     uint32_t li = P.rng % sv.light_count;
                     if (sv.light_is_sphere[li]) { rng_step(P.rng); rng_step(P.rng); rng_step(P.rng); rng_step(P.rng); }
                 }
-                bool is_trans;
-                V3 wi = sample_brdf(P.rng, n, P.wo, kRoughness, m, is_trans);
-                if (is_trans) P.org = add(P.org, scale(2.0f * kEps, P.dir)); /* ray.cpp:1345-1348: dir is still the arriving direction */
-                P.dir = wi;
-                return true;
+                draw = sample_brdf_draw(P.rng, kRoughness, m);
+                angle = draw.phi;
+            } else {
+                P.sample++;
+                P.ps = PS_SAMPLE;
             }
-            P.sample++;
-            P.ps = PS_SAMPLE;
         }
-        if (P.ps == PS_SAMPLE) {
+        if (!bounce) { /* P.ps == PS_SAMPLE */
             if (P.sample == P.spp) {
                 /* ray.cpp:1428 */
                 V3 o = divs(P.color, (float)P.spp);
@@ -466,19 +469,29 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderView &rv, PathState &P, 
             float fx = (2.0f * (int)(P.pxy & 0xffffu) / (float)rv.W) - 1.0f; /* i32 -> f32, as the reference's x, y */
             float fy = (2.0f * (int)(P.pxy >> 16) / (float)rv.H) - 1.0f;
             V3 to_pixel = normalize(sub(add(scale(fx, cam_x), scale(fy, cam_y)), cam_z));
-            V3 focal = add(cam_p, scale(focal_length, to_pixel));
-            /* ray.cpp:1232-1246 */
-            float rad = rng_between(P.rng, 0.0f, 2 * kPi);
-            V3 ap = sub(add(add(cam_p, scale(aperture * ort_cosf(rad), cam_x)), scale(aperture * ort_sinf(rad), cam_y)),
-                        scale(0.1f, cam_z));
+            focal = add(cam_p, scale(focal_length, to_pixel));
+            angle = rng_between(P.rng, 0.0f, 2 * kPi); /* ray.cpp:1232 */
+        }
+        /* lanes that bounce and lanes that start a new camera sample both need cos/sin of one angle
+           (lobe azimuth / aperture angle): the double-precision evaluation happens here once,
+           converged, instead of once in each branch (same operand, same bits) */
+        float cs = ort_cosf(angle), sn = ort_sinf(angle);
+        if (bounce) {
+            bool is_trans;
+            V3 wi = sample_brdf_finish(n, P.wo, m, draw, cs, sn, is_trans);
+            if (is_trans) P.org = add(P.org, scale(2.0f * kEps, P.dir)); /* ray.cpp:1345-1348: dir is still the arriving direction */
+            P.dir = wi;
+        } else {
+            /* ray.cpp:1233-1246 */
+            V3 ap = sub(add(add(cam_p, scale(aperture * cs, cam_x)), scale(aperture * sn, cam_y)), scale(0.1f, cam_z));
             P.dir = normalize(sub(focal, ap));
-            P.wo = neg(normalize(P.dir));
+            P.wo = neg(normalize(P.dir)); /* normalised again (sic) */
             P.org = ap;
             P.weight = mk(1, 1, 1);
             P.primary = true;
             P.ps = PS_HIT;
-            return true;
         }
+        return true;
     }
     return false;
 }
