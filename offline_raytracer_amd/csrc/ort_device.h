@@ -141,10 +141,15 @@ ORT_D Beer beer(V3 N, V3 wo, float ior) {                                       
     return r;
 }
 
+/* DIFFUSE_ONLY = compiled for a scene in which no material can enter the specular or the
+   transmission block (|Ks|^2 > 0, |Kt|^2 > 0, ps_c > 0, pt_c > 0 all false; checked on the host at
+   upload): those blocks are then dead code and dropping them frees registers.  Values are unchanged. */
+template <bool DIFFUSE_ONLY = false>
 ORT_D V3 eval_scattering(V3 N, V3 wi, V3 wo, const Mat &mt, float rough, float dist) { /* ray.cpp:936-1005 */
     V3 Ed = mt.ed; /* Kd / pi_32, per material */
     V3 Es = mk(0, 0, 0), Et = mk(0, 0, 0);
     float wi_n = dot(wi, N), wo_n = dot(wo, N);
+    if (DIFFUSE_ONLY) return scale(absr(wi_n), add(add(Ed, Es), Et));
     /* H is only consumed under "wi.H > 0 && |Ks|^2 > 0" (ray.cpp:949): not computed for Ks = 0 */
     if (len2(mt.ks) > 0.0f) {
         V3 H = scale(sgn(dot(wi, N)), normalize(add(wo, wi)));
@@ -183,11 +188,12 @@ ORT_D V3 eval_scattering(V3 N, V3 wi, V3 wo, const Mat &mt, float rough, float d
     return scale(absr(wi_n), add(add(Ed, Es), Et));
 }
 
+template <bool DIFFUSE_ONLY = false>
 ORT_D float pdf_brdf(V3 N, V3 wi, V3 wo, float rough, const Mat &mt) {            /* ray.cpp:1007-1063 */
     float pd_c = mt.pd_c, ps_c = mt.ps_c, pt_c = mt.pt_c; /* per material, ray.cpp:1010-1018 */
     float pd = absr(dot(wi, N)) / kPi;
     float ps = 0.0f;
-    if (ps_c > 0.0f) { /* H and its dot products are only consumed here */
+    if (!DIFFUSE_ONLY && ps_c > 0.0f) { /* H and its dot products are only consumed here */
         V3 H = scale(sgn(dot(N, wi)), normalize(add(wo, wi)));
         float n_h = dot(N, H), wi_h = dot(wi, H);
         float denom = (4.0f * absr(wi_h));
@@ -197,7 +203,7 @@ ORT_D float pdf_brdf(V3 N, V3 wi, V3 wo, float rough, const Mat &mt) {          
         }
     }
     float pt = ps;                                                                /* sic */
-    if (pt_c > 0.0f) { /* m and the radicand are only consumed under "pt_c > 0 && r >= 0" */
+    if (!DIFFUSE_ONLY && pt_c > 0.0f) { /* m and the radicand are only consumed under "pt_c > 0 && r >= 0" */
         Beer bn = beer(N, wo, mt.ior);
         V3 m = normalize(neg(add(scale(bn.ni, wi), scale(bn.no, wo))));
         float r = radicand(m, wo, bn.n);

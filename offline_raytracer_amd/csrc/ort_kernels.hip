@@ -98,6 +98,7 @@ struct DeviceScene {
     void *boxes = nullptr, *box_mat = nullptr, *cyls = nullptr, *cyl_mat = nullptr, *materials = nullptr;
     void *light_is_sphere = nullptr;
     uint32_t light_count = 0;
+    bool diffuse_only = false; /* no surface material can enter the specular / transmission blocks */
     void *ref_nodes = nullptr, *ref_recs = nullptr, *chain_boxes = nullptr;
     void *tri_chain = nullptr, *sphere_chain = nullptr, *box_chain = nullptr, *cyl_chain = nullptr;
     void *tri_order = nullptr, *sphere_order = nullptr, *box_order = nullptr, *cyl_order = nullptr;
@@ -335,7 +336,7 @@ ORT_D void resolve_hit(const SceneView &sv, V3 org, V3 dir, V3 inv_d, uint32_t l
 /* Advance the lane's path state machine until it has produced the next ray (returns true; the ray
    is P.org / P.dir) or has run out of work (returns false).  On entry with P.ps == PS_HIT, h holds
    the resolved closest hit of the ray produced by the previous call. */
-template <bool COUNTERS>
+template <bool COUNTERS, bool DIFFUSE = false>
 ORT_D bool produce_ray(const SceneView &sv, const RenderView &rv, PathState &P, const HitState &h, Counters &c) {
     const V3 cam_p = mk(sv.cam[0], sv.cam[1], sv.cam[2]);
     const V3 cam_x = mk(sv.cam[3], sv.cam[4], sv.cam[5]);
@@ -420,9 +421,9 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderView &rv, PathState &P, 
                     if (len2(m.kd) > 0.0f) P.weight = had(P.weight, m.kd); /* ray.cpp:1267-1270 */
                 } else {
                     /* ray.cpp:1374-1405: pdf and BSDF with the NEW surface's normal and material, the OLD wo (sic) */
-                    float p = pdf_brdf(n, P.dir, P.wo, kRoughness, m) * rv.rr;
+                    float p = pdf_brdf<DIFFUSE>(n, P.dir, P.wo, kRoughness, m) * rv.rr;
                     if (p > 0.000001f) {
-                        V3 f = eval_scattering(n, P.dir, P.wo, m, kRoughness, h.best_t);
+                        V3 f = eval_scattering<DIFFUSE>(n, P.dir, P.wo, m, kRoughness, h.best_t);
                         P.weight = had(divs(f, p), P.weight);
                     }
                     P.wo = neg(P.dir);
@@ -608,7 +609,7 @@ ORT_D void flush_counters(const RenderView &rv, const Counters &c, bool all) {
 }
 
 /* persistent mode: one lane runs jobs until the job space is empty */
-template <bool COUNTERS>
+template <bool COUNTERS, bool DIFFUSE = false>
 ORT_D void pt_lane(const SceneView &sv, const RenderView &rv, uint32_t *lds_stack, const int tid, const uint32_t lane_id) {
     uint32_t spill[kSpillStack];
     PathState P;
@@ -619,7 +620,7 @@ ORT_D void pt_lane(const SceneView &sv, const RenderView &rv, uint32_t *lds_stac
     for (;;) {
         if (!tracing) {
             if (P.ps == PS_HIT) resolve_hit<COUNTERS>(sv, P.org, P.dir, T.inv_d, lane_id, h, c);
-            tracing = produce_ray<COUNTERS>(sv, rv, P, h, c);
+            tracing = produce_ray<COUNTERS, DIFFUSE>(sv, rv, P, h, c);
             if (tracing) {
                 begin_ray(P, T, h);
                 if (COUNTERS) c.rays++;
@@ -712,11 +713,14 @@ ORT_D void combine_pixel(const RenderView &rv, unsigned long long idx) {
 #ifndef ORT_WAVES_PER_EU
 #define ORT_WAVES_PER_EU 4 /* VGPR budget: 4 waves/SIMD = 128 registers, 16 spilled (tuned on MI355X: profiles/r01_tuning.md) */
 #endif
-template <bool COUNTERS>
+/* DIFFUSE: every surface material of the uploaded scene has Ks = Kt = 0, so the evaluation and pdf
+   of the specular / transmission lobes are compiled out (sampling keeps all three lobes: a draw of
+   exactly 1.0 still takes the reference's transmission branch).  Same values, fewer registers. */
+template <bool COUNTERS, bool DIFFUSE>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(ORT_WAVES_PER_EU, ORT_WAVES_PER_EU)))
 pt_persistent(SceneView sv, RenderView rv) {
     __shared__ uint32_t lds_stack[kLdsStack * kBlock];
-    pt_lane<COUNTERS>(sv, rv, lds_stack, (int)threadIdx.x, blockIdx.x * (uint32_t)kBlock + threadIdx.x);
+    pt_lane<COUNTERS, DIFFUSE>(sv, rv, lds_stack, (int)threadIdx.x, blockIdx.x * (uint32_t)kBlock + threadIdx.x);
 }
 
 /* wavefront kernels: fixed-size grids, grid-stride over the slots (so a lane id < grid size indexes
@@ -894,6 +898,14 @@ int device_upload(Scene *scene, int device, std::string *err) {
     std::vector<DevMaterial> mats(scene->materials.size());
     for (size_t i = 0; i < mats.size(); ++i) mats[i] = make_dev_material(scene->materials[i]);
     if ((rc = upload_vec(mats, &d->materials, err))) return rc;
+    d->diffuse_only = true; /* the four guards of eval_scattering / pdf_brdf, for every material a path can scatter on */
+    for (size_t i = 1; i < mats.size(); ++i) {
+        const DevMaterial &dm = mats[i];
+        if (dm.is_light) continue;
+        const float ks2 = dm.specular[0] * dm.specular[0] + dm.specular[1] * dm.specular[1] + dm.specular[2] * dm.specular[2];
+        const float kt2 = dm.transmission[0] * dm.transmission[0] + dm.transmission[1] * dm.transmission[1] + dm.transmission[2] * dm.transmission[2];
+        if (ks2 > 0.0f || kt2 > 0.0f || dm.ps_c > 0.0f || dm.pt_c > 0.0f) d->diffuse_only = false;
+    }
     std::vector<uint32_t> lis(scene->lights.size());
     for (size_t i = 0; i < lis.size(); ++i) lis[i] = (scene->lights[i].type == 1u) ? 1u : 0u;
     d->light_count = (uint32_t)lis.size();
@@ -1097,8 +1109,11 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
         rc = counters ? launch_wavefront<true>(d, sv, rv, stream, err) : launch_wavefront<false>(d, sv, rv, stream, err);
         if (rc) return rc;
     } else {
-        if (counters) hipLaunchKernelGGL(pt_persistent<true>, dim3(grid), dim3(kBlock), 0, stream, sv, rv);
-        else hipLaunchKernelGGL(pt_persistent<false>, dim3(grid), dim3(kBlock), 0, stream, sv, rv);
+        const char *kenv = getenv("ORT_KERNEL"); /* "general" forces the all-lobes kernel (A/B runs; same results) */
+        const bool diffuse = d->diffuse_only && !(kenv && strcmp(kenv, "general") == 0);
+        if (counters) hipLaunchKernelGGL((pt_persistent<true, false>), dim3(grid), dim3(kBlock), 0, stream, sv, rv);
+        else if (diffuse) hipLaunchKernelGGL((pt_persistent<false, true>), dim3(grid), dim3(kBlock), 0, stream, sv, rv);
+        else hipLaunchKernelGGL((pt_persistent<false, false>), dim3(grid), dim3(kBlock), 0, stream, sv, rv);
         ORT_HIP(hipGetLastError());
     }
     if (rv.mode == JOBS_CHUNK) {

@@ -164,6 +164,18 @@ def test_wavefront_mode_equals_persistent_mode(api, gpu_scene, monkeypatch):
     assert_bits_equal(out, ref)
 
 
+@pytest.mark.parametrize("name", ["c3_bunny_room", "c4_dwarf_room"])
+def test_diffuse_kernel_equals_general_kernel(api, gpu_scene, monkeypatch, name):
+    """scenes whose materials all have Ks = Kt = 0 run the kernel compiled without the specular /
+    transmission evaluation; ORT_KERNEL=general forces the all-lobes kernel: same bits"""
+    scene = gpu_scene(name)
+    monkeypatch.delenv("ORT_KERNEL", raising=False)
+    a, _ = scene.render(160, 90, 32, 21, "chunk", chunk=8)
+    monkeypatch.setenv("ORT_KERNEL", "general")
+    b, _ = scene.render(160, 90, 32, 21, "chunk", chunk=8)
+    assert_bits_equal(a, b)
+
+
 def test_determinism(api, gpu_scene):
     scene = gpu_scene("testscene")
     a, _ = scene.render(128, 72, 8, 1, "chunk", chunk=4)

@@ -120,7 +120,8 @@ int main(int argc, char **argv) {
         }
         flush_counters(rv, c, true);
     } else
-    pt_lane<true>(sv, rv, lds.data(), 0, 0);
+    if (getenv("SIM_DIFFUSE")) pt_lane<true, true>(sv, rv, lds.data(), 0, 0); /* caller vouches for Ks = Kt = 0 */
+    else pt_lane<true>(sv, rv, lds.data(), 0, 0);
     if (rv.mode == JOBS_CHUNK)
         for (unsigned long long i = 0; i < (unsigned long long)rv.my_blocks * 64; ++i) combine_pixel(rv, i);
     double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
