@@ -32,7 +32,8 @@ using namespace ortd;
 constexpr int kBlock = 256;      /* 4 waves */
 constexpr int kLdsStack = 24;    /* entries per lane in LDS: 24 * 256 * 4 B = 24 KB per block */
 constexpr int kSpillStack = 40;  /* scratch tail; ort_tree.cpp bounds the depth at 60 */
-constexpr uint32_t kBfsQueue = 2048; /* live entries of the breadth-first fallback, per lane, in HBM */
+constexpr uint32_t kBfsPoolQueues = 256;      /* queues of the breadth-first fallback, shared by all lanes */
+constexpr size_t kBfsPoolBytes = 512u << 20; /* at most; a queue holds one entry per reference-tree node */
 
 struct SceneView {
     const float4 *nodes;      /* 4 per node */
@@ -54,8 +55,13 @@ struct SceneView {
     const float4 *chain_boxes; /* 2 per chain entry */
     const uint32_t *tri_chain, *sphere_chain, *box_chain, *cyl_chain;
     const uint32_t *tri_order, *sphere_order, *box_order, *cyl_order; /* reference test order (ties) */
-    uint32_t *bfs_queue;       /* kBfsQueue entries per lane: ring buffer of the exact fallback */
-    unsigned long long *fallback_counters; /* [0] rays re-cast exactly, [1] ring overflows */
+    /* exact fallback: a pool of queues in HBM, each long enough for every node of the reference tree
+       (a ray enqueues a node at most once), taken with a try-lock for the duration of one re-cast */
+    uint32_t *bfs_pool;
+    uint32_t *bfs_locks;
+    uint32_t bfs_queue_cap, bfs_queue_count;
+    unsigned long long *fallback_counters; /* [0] rays re-cast exactly, [1] queue overflows (cannot happen: kept as a tripwire) */
+    uint32_t force_fallback_mask; /* tests (ORT_DEBUG_FORCE_FALLBACK): also re-cast rays with (bits(dir.x) & mask) == 0; ~0u = off */
 };
 
 enum : int { JOBS_EXPLICIT = 0, JOBS_PIXEL = 1, JOBS_CHUNK = 2 };
@@ -102,7 +108,8 @@ struct DeviceScene {
     void *ref_nodes = nullptr, *ref_recs = nullptr, *chain_boxes = nullptr;
     void *tri_chain = nullptr, *sphere_chain = nullptr, *box_chain = nullptr, *cyl_chain = nullptr;
     void *tri_order = nullptr, *sphere_order = nullptr, *box_order = nullptr, *cyl_order = nullptr;
-    void *bfs_queue = nullptr;
+    void *bfs_pool = nullptr, *bfs_locks = nullptr;
+    uint32_t bfs_queue_cap = 0, bfs_queue_count = 0;
     unsigned int max_blocks = 0;
     unsigned long long *ctrl = nullptr; /* [0] next_job, [1..5] counters */
     float *partial = nullptr;
@@ -128,6 +135,11 @@ enum : int { PS_NEED_JOB = 0, PS_PIXEL = 1, PS_SAMPLE = 2, PS_HIT = 3, PS_DONE =
 #define ORT_POPC64(m) __builtin_popcountll(m)
 #define ORT_NEXT_JOB(p) ((*(p))++)
 #define ORT_COUNT(p, v) (*(p) += (v))
+#define ORT_TRY_LOCK(p) (*(p) == 0u ? (*(p) = 1u, true) : false)
+#define ORT_UNLOCK(p) (*(p) = 0u)
+#define ORT_FENCE()
+#define ORT_FFS64(m) __builtin_ffsll((long long)(m))
+#define ORT_LANE() 0
 #ifndef ORT_SIM_PIXEL_HOOK
 #define ORT_SIM_PIXEL_HOOK(x, y, rng)
 #endif
@@ -141,6 +153,11 @@ enum : int { PS_NEED_JOB = 0, PS_PIXEL = 1, PS_SAMPLE = 2, PS_HIT = 3, PS_DONE =
 #define ORT_POPC64(m) __popcll(m)
 #define ORT_NEXT_JOB(p) atomicAdd((p), 1ull)
 #define ORT_COUNT(p, v) atomicAdd((p), (v))
+#define ORT_TRY_LOCK(p) (atomicCAS((p), 0u, 1u) == 0u)
+#define ORT_UNLOCK(p) ((void)atomicExch((p), 0u))
+#define ORT_FENCE() __threadfence()
+#define ORT_FFS64(m) __ffsll((unsigned long long)(m))
+#define ORT_LANE() ((int)__lane_id())
 #endif
 
 
@@ -240,7 +257,7 @@ ORT_D bool chain_admits(const SceneView &sv, uint32_t prim, V3 org, V3 inv_d) {
    octree -- breadth-first, children in slot order, records in push order, a child admitted when
    the origin is inside it or 1e-6 <= t_entry < best AT THAT MOMENT.  The reference never reuses
    queue memory within a ray; the emulation keeps only the live entries in a ring in HBM.
-   Returns false if the ring overflowed (the render call then fails). */
+   Returns false if the queue overflowed (the render call then fails). */
 template <bool COUNTERS>
 ORT_D bool ref_raycast_bfs(const SceneView &sv, V3 org, V3 dir, V3 inv_d, uint32_t *queue, float &best_t, V3 &hit_n,
                            uint32_t &hit_prim, unsigned long long &c_nodes, unsigned long long &c_tris,
@@ -251,9 +268,10 @@ ORT_D bool ref_raycast_bfs(const SceneView &sv, V3 org, V3 dir, V3 inv_d, uint32
     float unused = 0;
     uint32_t head = 0, tail = 0;
     bool ok = true;
-    queue[tail++ & (kBfsQueue - 1u)] = 0;
+    const uint32_t cap = sv.bfs_queue_cap;
+    queue[tail++] = 0;
     while (head != tail) {
-        uint32_t node = queue[head++ & (kBfsQueue - 1u)];
+        uint32_t node = queue[head++];
         const float4 *np = sv.ref_nodes + 3u * node;
         float4 a = np[0], b = np[1], c = np[2];
         int32_t first_child = (int32_t)om_f32_bits(a.w);
@@ -279,8 +297,8 @@ ORT_D bool ref_raycast_bfs(const SceneView &sv, V3 org, V3 dir, V3 inv_d, uint32
                     add = (t >= kHitTMin && t < best_t);
                 }
                 if (add) {
-                    if (tail - head >= kBfsQueue) { ok = false; continue; }
-                    queue[tail++ & (kBfsQueue - 1u)] = ci;
+                    if (tail >= cap) { ok = false; continue; }
+                    queue[tail++] = ci;
                 }
             }
         }
@@ -325,11 +343,28 @@ ORT_D float *job_plane(const RenderView &rv, uint32_t plane) {
    phantom tangent hit could have won, re-cast the ray exactly. */
 template <bool COUNTERS>
 ORT_D void resolve_hit(const SceneView &sv, V3 org, V3 dir, V3 inv_d, uint32_t lane_id, HitState &h, Counters &c) {
-    if ((h.hit_prim != kNoPrim && !chain_admits(sv, h.hit_prim, org, inv_d)) || h.phantom_t <= h.best_t) {
-        ORT_COUNT(sv.fallback_counters, 1ull); /* rare: straight to memory, no register kept across the loop */
-        if (!ref_raycast_bfs<COUNTERS>(sv, org, dir, inv_d, sv.bfs_queue + (size_t)lane_id * kBfsQueue, h.best_t, h.hit_n, h.hit_prim,
-                                       c.nodes, c.tris, c.analytic))
-            ORT_COUNT(sv.fallback_counters + 1, 1ull);
+    const bool need = (h.hit_prim != kNoPrim && !chain_admits(sv, h.hit_prim, org, inv_d)) || h.phantom_t <= h.best_t ||
+                      (sv.force_fallback_mask != 0xffffffffu && (om_f32_bits(dir.x) & sv.force_fallback_mask) == 0u);
+    /* Rare.  The lanes of a wave that need the re-cast take turns (wave-uniform loop over the ballot), so
+       a wave never has more than one lane holding or waiting for a queue of the pool: a waiting lane can
+       only wait for holders in other waves, which are running, never for a lane of its own wave parked at a
+       reconvergence point.  The fences order the queue's contents across holders on different XCDs
+       (each XCD has its own L2). */
+    unsigned long long pending = ORT_BALLOT(need);
+    while (pending) {
+        const int leader = ORT_FFS64(pending) - 1;
+        if (ORT_LANE() == leader) {
+            ORT_COUNT(sv.fallback_counters, 1ull); /* straight to memory, no register kept across the loop */
+            uint32_t slot = ((lane_id * 2654435761u) >> 8) % sv.bfs_queue_count;
+            while (!ORT_TRY_LOCK(sv.bfs_locks + slot)) slot = (slot + 1u) % sv.bfs_queue_count;
+            ORT_FENCE();
+            if (!ref_raycast_bfs<COUNTERS>(sv, org, dir, inv_d, sv.bfs_pool + (size_t)slot * sv.bfs_queue_cap, h.best_t, h.hit_n,
+                                           h.hit_prim, c.nodes, c.tris, c.analytic))
+                ORT_COUNT(sv.fallback_counters + 1, 1ull);
+            ORT_FENCE();
+            ORT_UNLOCK(sv.bfs_locks + slot);
+        }
+        pending &= pending - 1ull;
     }
 }
 
@@ -863,7 +898,7 @@ void device_release(Scene *scene) {
     (void)hipSetDevice(d->device);
     void *ptrs[] = {d->nodes, d->tris, d->tri_mat, d->spheres, d->sphere_mat, d->boxes, d->box_mat, d->cyls, d->cyl_mat,
                     d->materials, d->light_is_sphere, d->ref_nodes, d->ref_recs, d->chain_boxes, d->tri_chain, d->sphere_chain,
-                    d->box_chain, d->cyl_chain, d->tri_order, d->sphere_order, d->box_order, d->cyl_order, d->bfs_queue, d->ctrl, d->partial, d->staging, d->jobs, d->states};
+                    d->box_chain, d->cyl_chain, d->tri_order, d->sphere_order, d->box_order, d->cyl_order, d->bfs_pool, d->bfs_locks, d->ctrl, d->partial, d->staging, d->jobs, d->states};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (d->wf_mem) (void)hipFree(d->wf_mem);
@@ -929,10 +964,15 @@ int device_upload(Scene *scene, int device, std::string *err) {
     hipDeviceProp_t prop;
     ORT_HIP(hipGetDeviceProperties(&prop, device));
     d->cu_count = prop.multiProcessorCount;
-    /* persistent grid: 4 workgroups of 256 lanes per CU; one fallback ring per lane (8 KB, 2 GB total) */
+    /* persistent grid: 4 workgroups of 256 lanes per CU */
     d->max_blocks = (unsigned int)(d->cu_count > 0 ? d->cu_count : 256) * 4u;
-    /* one fallback ring per resident lane of the widest grid (wavefront trace: 8 workgroups per CU); 4 GB */
-    ORT_HIP(hipMalloc(&d->bfs_queue, (size_t)d->max_blocks * 2u * kBlock * kBfsQueue * sizeof(uint32_t)));
+    /* fallback queues: one entry per reference-tree node each, as many as fit the budget */
+    d->bfs_queue_cap = (uint32_t)rt.nodes.size() + 8u;
+    size_t fit = kBfsPoolBytes / ((size_t)d->bfs_queue_cap * sizeof(uint32_t));
+    d->bfs_queue_count = (uint32_t)(fit < 16 ? 16 : (fit > kBfsPoolQueues ? kBfsPoolQueues : fit));
+    ORT_HIP(hipMalloc(&d->bfs_pool, (size_t)d->bfs_queue_count * d->bfs_queue_cap * sizeof(uint32_t)));
+    ORT_HIP(hipMalloc(&d->bfs_locks, (size_t)d->bfs_queue_count * sizeof(uint32_t)));
+    ORT_HIP(hipMemset(d->bfs_locks, 0, (size_t)d->bfs_queue_count * sizeof(uint32_t)));
     ORT_HIP(hipHostMalloc((void **)&d->h_active, sizeof(unsigned long long)));
     return ORT_OK;
 }
@@ -1046,7 +1086,12 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
     sv.box_chain = (const uint32_t *)d->box_chain; sv.cyl_chain = (const uint32_t *)d->cyl_chain;
     sv.tri_order = (const uint32_t *)d->tri_order; sv.sphere_order = (const uint32_t *)d->sphere_order;
     sv.box_order = (const uint32_t *)d->box_order; sv.cyl_order = (const uint32_t *)d->cyl_order;
-    sv.bfs_queue = (uint32_t *)d->bfs_queue;
+    sv.bfs_pool = (uint32_t *)d->bfs_pool;
+    sv.bfs_locks = (uint32_t *)d->bfs_locks;
+    sv.bfs_queue_cap = d->bfs_queue_cap;
+    sv.bfs_queue_count = d->bfs_queue_count;
+    const char *ff = getenv("ORT_DEBUG_FORCE_FALLBACK");
+    sv.force_fallback_mask = ff ? (uint32_t)strtoul(ff, nullptr, 0) : 0xffffffffu;
     sv.fallback_counters = d->ctrl + 6;
     ort_camera cam;
     camera_basis(*scene, p->width, p->height, &cam);
@@ -1132,7 +1177,7 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
         ORT_HIP(hipStreamSynchronize(stream));
         unsigned long long ovf = 0;
         ORT_HIP(hipMemcpy(&ovf, d->ctrl + 7, sizeof(ovf), hipMemcpyDeviceToHost));
-        if (ovf) { *err = "reference-order fallback queue overflowed (scene too deep for kBfsQueue)"; return ORT_ERR_UNSUPPORTED; }
+        if (ovf) { *err = "reference-order fallback queue overflowed"; return ORT_ERR_UNSUPPORTED; }
     }
     if (stats) {
         memset(stats, 0, sizeof(*stats));

@@ -44,11 +44,18 @@ _scene_cache = {}
 
 
 @pytest.fixture(scope="session")
-def load_scene(api):
-    """name -> committed product scene (cached per session)."""
+def load_scene(api, tmp_path_factory):
+    """name -> committed product scene (cached per session).  "c5_heightfield_<n>" (BASELINE.json's
+    synthetic-mesh stress config) is generated on the spot by tools/make_heightfield.py."""
     def _load(name):
         if name not in _scene_cache:
-            _scene_cache[name] = api.Scene.load_scn(os.path.join(DATA, name + ".scn")).commit()
+            if name.startswith("c5_heightfield_"):
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import make_heightfield
+                scn, _, _ = make_heightfield.write_scene(int(name.rsplit("_", 1)[1]), str(tmp_path_factory.mktemp("c5")))
+            else:
+                scn = os.path.join(DATA, name + ".scn")
+            _scene_cache[name] = api.Scene.load_scn(scn).commit()
         return _scene_cache[name]
     return _load
 

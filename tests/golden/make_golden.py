@@ -172,7 +172,41 @@ def make_unit_inputs():
     return np.concatenate(recs)
 
 
+def golden_c5(manifest):
+    """C5 (BASELINE.json configs[4]) on its 99 458-triangle decimation, the size the reference build can
+    hold (at n = 708 its fixed arenas overflow): generated mesh -> reference loader, octree, renders."""
+    import hashlib
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_heightfield
+    n = 224
+    scn, nv, nf = make_heightfield.write_scene(n, TMP)
+    base = TMP + "/"
+    name = "c5_heightfield_%d" % n
+    dump = os.path.join(TMP, name + ".dump")
+    info = run(REF_DET, "scene-dump", scn, base, 64, 48, dump)
+    dg = ref_io.scene_digest(ref_io.read_scene_dump(dump))
+    dg["octree"] = info
+    dg["ply_sha256"] = hashlib.sha256(open(os.path.join(TMP, name + ".ply"), "rb").read()).hexdigest()
+    dg["vertices"], dg["triangles"] = nv, nf
+    manifest["scenes"][name] = dg
+    manifest["renders"] = [e for e in manifest["renders"] if e["scene"] != name]
+    arrays = {}
+    for policy, W, H, spp, chunk, seed in [("pixel", 64, 48, 4, 1, 99), ("chunk", 40, 30, 4, 2, 7), ("tile32", 64, 64, 1, 1, 12345)]:
+        out = os.path.join(TMP, "r.f32")
+        js = run(REF_DET, "render", scn, base, W, H, spp, seed, policy, out, chunk)
+        key = "%s_%dx%d_%dspp_c%d_s%d" % (policy, W, H, spp, chunk, seed)
+        arrays[key] = np.fromfile(out, "<f4").reshape(H, W, 3)
+        manifest["renders"].append(dict(scene=name, key=key, policy=policy, width=W, height=H, spp=spp, chunk=chunk, seed=seed,
+                                        shapes_tested=js["shapes_tested"], final_rng=js["final_rng"]))
+    np.savez_compressed(os.path.join(HERE, "renders_%s.npz" % name), **arrays)
+
+
 def main():
+    if "--only-c5" in sys.argv:  # add / refresh the C5 fixtures without touching the others
+        manifest = json.load(open(os.path.join(HERE, "manifest.json")))
+        golden_c5(manifest)
+        json.dump(manifest, open(os.path.join(HERE, "manifest.json"), "w"), indent=1, sort_keys=True)
+        return
     for b in (REF_DET, REF_GLIBC):
         if not os.path.exists(b):
             sys.exit("missing %s: run `make -C oracle ref` in the dev container first" % b)
@@ -250,6 +284,8 @@ def main():
         run(REF_DET, "raycast", scn, DATA, os.path.join(TMP, "rays.bin"), os.path.join(TMP, "hits.bin"))
         hits = np.fromfile(os.path.join(TMP, "hits.bin"), dtype=np.dtype([("t", "<f4"), ("n", "<f4", 3), ("mat", "<u4")]))
         np.savez_compressed(os.path.join(HERE, "raycast_%s.npz" % name), rays=rays, t=hits["t"], n=hits["n"], mat=hits["mat"])
+
+    golden_c5(manifest)
 
     # cross-check values recorded by the survey, re-measured here on ref_glibc
     js = run(REF_GLIBC, "render", DATA + "testscene.scn", DATA, 64, 64, 4, 12345, "whole", os.path.join(TMP, "x.f32"))

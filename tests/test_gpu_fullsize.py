@@ -52,3 +52,51 @@ def test_headline_config_chunk_composition(api, gpu_scene):
     assert np.isfinite(win).all() and win.max() > 0
     # the 16-chunk mean stays close to its first chunk (same scene, 16x more samples): sanity, not parity
     assert abs(float(win.mean()) - float(k0[rect[1]:rect[3], rect[0]:rect[2]].mean())) < 0.05
+
+
+# ---- BASELINE.json configs[3] and [4]: 3840x2160 -------------------------------------------------
+W4, H4 = 3840, 2160
+
+
+def test_c4_dwarf_4k_windows_match_oracle(api, oracle, gpu_scene):
+    """dwarf.obj room at 3840x2160 (the 8-GPU config): windows of the full frame against the oracle,
+    and the 8-way shard union of the frame equals the single-GPU frame"""
+    scene = gpu_scene("c4_dwarf_room")
+    spp, chunk, seed = 8, 4, 12345
+    img, st = scene.render(W4, H4, spp, seed, "chunk", chunk=chunk, counters=True)
+    assert st["paths"] == W4 * H4 * spp
+    osc = oracle.OracleScene(scene.flatten(W4, H4))
+    for (x0, y0) in [(1900, 1000), (200, 1800), (3000, 120)]:
+        rect = (x0, y0, x0 + 24, y0 + 16)
+        ref, _ = osc.render(W4, H4, spp, seed, "chunk", chunk=chunk, rect=rect, threads=16)
+        assert_bits_equal(img[rect[1]:rect[3], rect[0]:rect[2]], ref[rect[1]:rect[3], rect[0]:rect[2]], "window %s" % (rect,))
+    acc = np.zeros_like(img)
+    for r in range(8):
+        part, _ = scene.render(W4, H4, spp, seed, "chunk", chunk=chunk, shard=(r, 8))
+        acc += part
+    assert_bits_equal(acc, img, "8-way shard union")
+
+
+def test_c5_million_triangle_mesh(api, oracle, gpu_scene):
+    """the 999 698-triangle height field (deep-tree stress config) at 3840x2160.  The reference build
+    cannot hold this mesh (its fixed arenas overflow), so the full size is pinned by the oracle
+    -- itself pinned by the reference on the 99 458-triangle decimation (golden fixtures) -- on windows
+    of the frame, plus determinism and shard composition."""
+    scene = gpu_scene("c5_heightfield_708")
+    assert scene.info().triangle_count == 999698
+    spp, chunk, seed = 4, 2, 12345
+    img, st = scene.render(W4, H4, spp, seed, "chunk", chunk=chunk, counters=True)
+    assert st["paths"] == W4 * H4 * spp
+    assert np.isfinite(img).all()
+    again, _ = scene.render(W4, H4, spp, seed, "chunk", chunk=chunk)
+    assert_bits_equal(img, again, "two runs")
+    osc = oracle.OracleScene(scene.flatten(W4, H4))
+    for (x0, y0) in [(1900, 1000), (1500, 1200), (2400, 900), (300, 300)]:
+        rect = (x0, y0, x0 + 16, y0 + 8)
+        ref, _ = osc.render(W4, H4, spp, seed, "chunk", chunk=chunk, rect=rect, threads=16)
+        assert_bits_equal(img[rect[1]:rect[3], rect[0]:rect[2]], ref[rect[1]:rect[3], rect[0]:rect[2]], "window %s" % (rect,))
+    acc = np.zeros_like(img)
+    for r in range(2):
+        part, _ = scene.render(W4, H4, spp, seed, "chunk", chunk=chunk, shard=(r, 2))
+        acc += part
+    assert_bits_equal(acc, img, "2-way shard union")

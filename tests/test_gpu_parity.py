@@ -13,6 +13,8 @@ from conftest import GOLDEN, assert_bits_equal
 pytestmark = pytest.mark.gpu
 
 SCENES = ["testscene", "c2_analytic", "c3_bunny_room", "c4_dwarf_room", "letters", "glass_room"]
+# + the 99 458-triangle decimation of BASELINE.json's synthetic-mesh config (generated, see conftest.load_scene)
+SCENES_C5 = SCENES + ["c5_heightfield_224"]
 
 
 def test_device_present(api):
@@ -58,7 +60,7 @@ def test_ieee_arithmetic_and_rng_on_device(api, oracle):
 
 
 # ---- renders ---------------------------------------------------------------------------------
-@pytest.mark.parametrize("name", SCENES)
+@pytest.mark.parametrize("name", SCENES_C5)
 def test_renders_match_reference_goldens(api, manifest, gpu_scene, name):
     """GPU image == the reference's own image (golden), every seeding policy."""
     z = np.load(os.path.join(GOLDEN, "renders_%s.npz" % name))
@@ -69,7 +71,7 @@ def test_renders_match_reference_goldens(api, manifest, gpu_scene, name):
         assert_bits_equal(img, z[e["key"]], "%s %s" % (name, e["key"]))
 
 
-@pytest.mark.parametrize("name", SCENES)
+@pytest.mark.parametrize("name", SCENES_C5)
 @pytest.mark.parametrize("policy,w,h,spp,chunk", [("chunk", 96, 64, 16, 4), ("pixel", 80, 50, 6, 0), ("chunk", 37, 23, 5, 1)])
 def test_renders_match_oracle(api, oracle, gpu_scene, name, policy, w, h, spp, chunk):
     scene = gpu_scene(name)
@@ -204,6 +206,24 @@ def test_exactness_fallback_is_exercised(api, oracle, gpu_scene):
     ref, _ = oracle.OracleScene(scene.flatten(w, h)).render(w, h, spp, 7, "chunk", chunk=4, threads=16)
     assert st["fallback_rays"] > 0
     assert_bits_equal(img, ref)
+
+
+@pytest.mark.parametrize("name", ["testscene", "c3_bunny_room", "glass_room", "c5_heightfield_224"])
+def test_every_ray_through_the_reference_order_walk(api, oracle, gpu_scene, monkeypatch, name):
+    """ORT_DEBUG_FORCE_FALLBACK=0 sends EVERY ray through the breadth-first emulation of raycast_bvh
+    (ray.cpp:624-822) on the device: same image, and thousands of lanes contend for the pooled queues;
+    mask 0xf re-casts ~1/16 of the rays, mixing both walks inside a wave."""
+    scene = gpu_scene(name)
+    w, h, spp = 64, 40, 4
+    ref, ost = oracle.OracleScene(scene.flatten(w, h)).render(w, h, spp, 77, "chunk", chunk=2, threads=16)
+    monkeypatch.setenv("ORT_DEBUG_FORCE_FALLBACK", "0")
+    img, st = scene.render(w, h, spp, 77, "chunk", chunk=2, counters=True)
+    assert st["fallback_rays"] == st["rays"] == ost["rays"]
+    assert_bits_equal(img, ref, "all rays re-cast")
+    monkeypatch.setenv("ORT_DEBUG_FORCE_FALLBACK", "0xf")
+    img, st = scene.render(w, h, spp, 77, "chunk", chunk=2, counters=True)
+    assert 0 < st["fallback_rays"] < st["rays"]
+    assert_bits_equal(img, ref, "1/16 of the rays re-cast")
 
 
 # ---- synthetic scenes / edge cases -----------------------------------------------------------------

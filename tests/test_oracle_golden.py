@@ -10,6 +10,8 @@ import ref_io
 from conftest import GOLDEN, assert_bits_equal
 
 SCENES = ["testscene", "c2_analytic", "c3_bunny_room", "c4_dwarf_room", "letters", "glass_room"]
+# + the 99 458-triangle decimation of BASELINE.json's synthetic-mesh config (generated, see conftest.load_scene)
+SCENES_C5 = SCENES + ["c5_heightfield_224"]
 
 
 @pytest.mark.parametrize("seed", [12345, 1, 4294967295, 2463534242])
@@ -55,7 +57,7 @@ def test_libm_is_close_to_glibc():
     assert ulp[finite].max() <= 1
 
 
-@pytest.mark.parametrize("name", SCENES)
+@pytest.mark.parametrize("name", SCENES_C5)
 def test_octree_matches_reference(oracle, manifest, name, load_scene):
     """the restated loose octree (ray.cpp:1468-2045) has the reference's node/leaf/byte counts."""
     flat = load_scene(name).flatten(64, 48)
@@ -66,7 +68,7 @@ def test_octree_matches_reference(oracle, manifest, name, load_scene):
     assert st["record_bytes"] == want["record_bytes"]
 
 
-@pytest.mark.parametrize("name", SCENES)
+@pytest.mark.parametrize("name", SCENES_C5)
 def test_renders_match_reference(oracle, manifest, name, load_scene):
     """full renders in every seeding policy: image bits, shapes-tested counter, final RNG state."""
     z = np.load(os.path.join(GOLDEN, "renders_%s.npz" % name))

@@ -98,8 +98,12 @@ int main(int argc, char **argv) {
     if (getenv("SIM_DUMP_RNG")) { g_pixel_rng = pix_rng.data(); g_W = W; }
     std::vector<uint32_t> lds(kLdsStack * kBlock);
     auto t0 = std::chrono::steady_clock::now();
-    std::vector<uint32_t> bfsq(kBfsQueue);
-    sv.bfs_queue = bfsq.data();
+    std::vector<uint32_t> bfsq(scene->ref.nodes.size() + 8), bfs_lock(1, 0u);
+    sv.bfs_pool = bfsq.data();
+    sv.bfs_locks = bfs_lock.data();
+    sv.bfs_queue_cap = (uint32_t)bfsq.size();
+    sv.bfs_queue_count = 1;
+    sv.force_fallback_mask = getenv("SIM_FORCE_FALLBACK") ? (uint32_t)strtoul(getenv("SIM_FORCE_FALLBACK"), 0, 0) : 0xffffffffu;
     if (getenv("SIM_WAVEFRONT")) {
         /* the wavefront schedule with a small slot pool: shade all slots, trace all slots, repeat */
         uint32_t S = (uint32_t)atoi(getenv("SIM_WAVEFRONT"));
