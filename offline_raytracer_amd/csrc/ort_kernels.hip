@@ -228,13 +228,10 @@ ORT_D bool ref_node_admits(V3 lo, V3 hi, V3 org, V3 inv_d) {
 }
 
 /* would the reference have reached this primitive?  Every node box on the way down must admit the
-   ray.  Entries are fetched four at a time so the (divergent, L2-latency-bound) loads overlap. */
-ORT_D bool chain_admits(const SceneView &sv, uint32_t prim, V3 org, V3 inv_d) {
-    uint32_t kind = prim >> 28, slot = prim & 0x00ffffffu;
-    uint32_t word = (kind == PRIM_TRI) ? sv.tri_chain[slot]
-                  : (kind == PRIM_SPHERE) ? sv.sphere_chain[slot]
-                  : (kind == PRIM_BOX) ? sv.box_chain[slot] : sv.cyl_chain[slot];
-    uint32_t len = word >> 28, first = word & 0x0fffffffu;
+   ray (origin inside, half-open; or entered at t >= 1e-6).  Entries run from the primitive's own node
+   (entry 0, the smallest box) up to the root's child.  chain_admits_full tests them all, four at a
+   time so the (divergent, L2-latency-bound) loads overlap. */
+ORT_D bool chain_admits_full(const SceneView &sv, uint32_t first, uint32_t len, V3 org, V3 inv_d) {
     bool ok = true;
     for (uint32_t base = 0; base < len; base += 4u) {
         float4 lo[4], hi[4];
@@ -251,6 +248,63 @@ ORT_D bool chain_admits(const SceneView &sv, uint32_t prim, V3 org, V3 inv_d) {
         if (!ok) break;
     }
     return ok;
+}
+
+ORT_D bool in_rect_half_open(float4 lo, float4 hi, V3 org) { /* math.h:1156-1169 */
+    return (org.x >= lo.x && org.x < hi.x) && (org.y >= lo.y && org.y < hi.y) && (org.z >= lo.z && org.z < hi.z);
+}
+
+/* The octree's boxes are nested (a shape grows every node it is pushed through, ray.cpp:1799-1948;
+   ort_reftree.cpp verifies it per chain and sets kChainNested).  With nested boxes B_top >= ... >= B_0
+   and a finite 1/d the admission tests are monotone: "origin inside" can only turn false going down, the
+   entry distance max_a min(t_lo, t_hi) can only grow (each per-axis near distance is a monotone float
+   function of the box bound) and the exit distance can only shrink.  So with B_j the first box from the
+   top that does not contain the origin, the whole chain admits the ray  <=>  B_j and B_0 do: boxes above
+   B_j contain the origin; boxes between are entered no earlier than B_j and are hit if B_0 is.
+   Two slab tests instead of one per level. */
+constexpr uint32_t kChainNested = 0x08000000u;
+#if defined(ORT_HOST_SIM) && defined(ORT_CHAIN_CROSSCHECK)
+static unsigned long long g_chain_crosschecks = 0;
+#endif
+ORT_D bool chain_admits(const SceneView &sv, uint32_t prim, V3 org, V3 inv_d) {
+    uint32_t kind = prim >> 28, slot = prim & 0x00ffffffu;
+    uint32_t word = (kind == PRIM_TRI) ? sv.tri_chain[slot]
+                  : (kind == PRIM_SPHERE) ? sv.sphere_chain[slot]
+                  : (kind == PRIM_BOX) ? sv.box_chain[slot] : sv.cyl_chain[slot];
+    const uint32_t len = word >> 28, first = word & 0x07ffffffu;
+    if (len == 0u) return true;
+    const bool finite = (om_f32_bits(inv_d.x) & 0x7fffffffu) < 0x7f800000u && (om_f32_bits(inv_d.y) & 0x7fffffffu) < 0x7f800000u &&
+                        (om_f32_bits(inv_d.z) & 0x7fffffffu) < 0x7f800000u;
+    if (!(word & kChainNested) || !finite) return chain_admits_full(sv, first, len, org, inv_d);
+    const float4 dlo = sv.chain_boxes[2u * first], dhi = sv.chain_boxes[2u * first + 1u];
+    float4 jlo = dlo, jhi = dhi;
+    bool found = false;
+#ifndef ORT_CHAIN_ROUND
+#define ORT_CHAIN_ROUND 2 /* boxes fetched per step from the top (2: 2210, 3: 2183, 4: 2166 Mpaths/s on the bunny room) */
+#endif
+    for (int32_t top = (int32_t)len - 1; !found && top >= 0; top -= ORT_CHAIN_ROUND) {
+        float4 lo[ORT_CHAIN_ROUND], hi[ORT_CHAIN_ROUND];
+#pragma unroll
+        for (int32_t k = 0; k < ORT_CHAIN_ROUND; ++k) {
+            int32_t i = top - k;
+            i = (i > 0) ? i : 0; /* clamp: re-tests entry 0, harmless */
+            lo[k] = sv.chain_boxes[2u * (first + (uint32_t)i)];
+            hi[k] = sv.chain_boxes[2u * (first + (uint32_t)i) + 1u];
+        }
+#pragma unroll
+        for (int32_t k = 0; k < ORT_CHAIN_ROUND; ++k) {
+            const bool outside = !in_rect_half_open(lo[k], hi[k], org);
+            if (!found && outside) { jlo = lo[k]; jhi = hi[k]; found = true; }
+        }
+    }
+    /* !found: the origin is inside every box of the chain */
+    const bool admits = !found || (hit_aab_t(mk(jlo.x, jlo.y, jlo.z), mk(jhi.x, jhi.y, jhi.z), org, inv_d) >= kHitTMin &&
+                                   ref_node_admits(mk(dlo.x, dlo.y, dlo.z), mk(dhi.x, dhi.y, dhi.z), org, inv_d));
+#if defined(ORT_HOST_SIM) && defined(ORT_CHAIN_CROSSCHECK) /* tools/host_sim: the shortcut against the full walk, every ray */
+    if (admits != chain_admits_full(sv, first, len, org, inv_d)) { fprintf(stderr, "chain shortcut disagrees with the full walk\n"); abort(); }
+    g_chain_crosschecks++;
+#endif
+    return admits;
 }
 
 /* exact fallback: raycast_bvh (ray.cpp:624-822) emulated literally on the reference-compatible

@@ -245,8 +245,21 @@ int build_ref_tree(Scene *scene, std::string *err) {
                 out->chain_boxes.push_back(F4{an.hi.x, an.hi.y, an.hi.z, 0});
                 ++len;
             }
-            if (len > 15 || first > 0x0fffffffu) { *err = "reference octree chain does not fit its encoding"; return ORT_ERR_UNSUPPORTED; }
-            uint32_t word = (len << 28) | first;
+            if (len > 15 || first > 0x07ffffffu) { *err = "reference octree chain does not fit its encoding"; return ORT_ERR_UNSUPPORTED; }
+            /* bit 27: every box lies within the next one up and has lo <= hi (always so for this
+               octree -- a shape grows each node it passes -- but the kernel's two-test shortcut
+               depends on it, so it is verified rather than assumed) */
+            bool nested = true;
+            for (uint32_t k = 0; k < len; ++k) {
+                const F4 &lo = out->chain_boxes[2u * (first + k)], &hi = out->chain_boxes[2u * (first + k) + 1u];
+                if (!(lo.x <= hi.x && lo.y <= hi.y && lo.z <= hi.z)) nested = false;
+                if (k + 1 < len) {
+                    const F4 &ulo = out->chain_boxes[2u * (first + k + 1u)], &uhi = out->chain_boxes[2u * (first + k + 1u) + 1u];
+                    if (!(lo.x >= ulo.x && lo.y >= ulo.y && lo.z >= ulo.z && hi.x <= uhi.x && hi.y <= uhi.y && hi.z <= uhi.z)) nested = false;
+                }
+            }
+            if (!nested) out->unnested_chains++;
+            uint32_t word = (len << 28) | (nested ? 0x08000000u : 0u) | first;
             for (size_t r = d.rec_first; r < out->recs.size(); ++r) {
                 uint32_t kind = out->recs[r] >> 28, slot = out->recs[r] & 0x00ffffffu;
                 if (kind == PRIM_TRI) out->tri_chain[slot] = word;

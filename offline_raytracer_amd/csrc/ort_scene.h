@@ -117,6 +117,7 @@ struct RefTree {
        distances the first one tested wins (strict <, ray.cpp:653,670,686,708) */
     std::vector<uint32_t> tri_order, sphere_order, box_order, cyl_order;
     uint32_t nonempty_leaves = 0, max_leaf_records = 0;
+    uint32_t unnested_chains = 0; /* chains whose boxes are not nested (expected 0; those take the full walk) */
     bool built = false;
 };
 

@@ -131,6 +131,9 @@ int main(int argc, char **argv) {
     double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     fprintf(stderr, "sim: %.2fs paths %llu rays %llu node_tests %llu tri_tests %llu analytic %llu fallback %llu overflow %llu%s\n", sec, ctrl[1], ctrl[2], ctrl[3], ctrl[4], ctrl[5], ctrl[6], ctrl[7],
             finals.empty() ? "" : (" final_rng " + std::to_string(finals.back())).c_str());
+#ifdef ORT_CHAIN_CROSSCHECK
+    fprintf(stderr, "chain shortcut == full walk on %llu rays; unnested chains %u\n", g_chain_crosschecks, scene->ref.unnested_chains);
+#endif
     if (g_ray_log) fclose(g_ray_log);
     if (g_pixel_rng) { FILE *g = fopen(getenv("SIM_DUMP_RNG"), "wb"); fwrite(pix_rng.data(), 4, pix_rng.size(), g); fclose(g); }
     FILE *f = fopen(argv[9], "wb");
