@@ -435,51 +435,6 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderView &rv, PathState &P, 
     const float aperture = 0.1f;                                /* ray.cpp:1199 */
 
     while (P.ps != PS_DONE) {
-        if (P.ps == PS_NEED_JOB) {
-            unsigned long long j = ORT_NEXT_JOB(rv.next_job);
-            if (j >= rv.job_count) { P.ps = PS_DONE; break; }
-            if (rv.mode == JOBS_EXPLICIT) {
-                ort_tile_job jb = rv.jobs[j];
-                P.job_index = (uint32_t)j;
-                P.jxx = (uint32_t)jb.x0 | ((uint32_t)jb.x1 << 16);
-                P.jyp = (uint32_t)jb.y1;
-                P.pxy = (uint32_t)jb.x0 | ((uint32_t)jb.y0 << 16);
-                P.rng = jb.rng_state; P.spp = jb.spp;
-                if (jb.x1 <= jb.x0 || jb.y1 <= jb.y0) { /* empty rect: the reference loops zero times */
-                    if (rv.final_states) rv.final_states[P.job_index] = P.rng;
-                    continue;
-                }
-            } else {
-                /* implicit job space: [chunk k][my 8x8 block b][pixel-in-block p] */
-                unsigned long long per_chunk = (unsigned long long)rv.my_blocks * 64ull;
-                uint32_t k = (uint32_t)(j / per_chunk);
-                uint32_t rem = (uint32_t)(j % per_chunk);
-                uint32_t blk = rv.shard_index + (rem >> 6) * rv.shard_count;
-                uint32_t pin = rem & 63u;
-                int x = (int)((blk % rv.blocks_w) * 8u + (pin & 7u));
-                int y = (int)((blk / rv.blocks_w) * 8u + (pin >> 3));
-                if (x < rv.x0 || x >= rv.x1 || y < rv.y0 || y >= rv.y1) continue;
-                uint32_t pix = (uint32_t)(y * rv.W + x);
-                P.jxx = (uint32_t)x | ((uint32_t)(x + 1) << 16);
-                P.pxy = (uint32_t)x | ((uint32_t)y << 16);
-                if (rv.mode == JOBS_PIXEL) {
-                    P.rng = job_seed(rv.seed, pix);
-                    P.spp = rv.spp;
-                    P.jyp = (uint32_t)(y + 1);
-                } else {
-                    P.rng = job_seed(rv.seed, k * (uint32_t)(rv.W * rv.H) + pix);
-                    P.spp = rv.chunk;
-                    P.jyp = (uint32_t)(y + 1) | (k << 16);
-                }
-            }
-            P.ps = PS_PIXEL;
-        }
-        if (P.ps == PS_PIXEL) {
-            ORT_SIM_PIXEL_HOOK((int)(P.pxy & 0xffffu), (int)(P.pxy >> 16), P.rng);
-            P.color = mk(0, 0, 0); /* ray.cpp:1211 */
-            P.sample = 0;
-            P.ps = PS_SAMPLE;
-        }
         bool bounce = false;
         float angle = 0.0f;
         BrdfDraw draw;
@@ -536,8 +491,11 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderView &rv, PathState &P, 
                 P.ps = PS_SAMPLE;
             }
         }
-        if (!bounce) { /* P.ps == PS_SAMPLE */
-            if (P.sample == P.spp) {
+        if (!bounce) {
+            /* a lane arrives here after its sample ended (PS_SAMPLE), or with nothing yet (PS_NEED_JOB).
+               Pixel write-back, next pixel / next job and the new camera ray all happen in this same
+               pass, so the rest of the wave does not wait through a second trip round the loop. */
+            if (P.ps == PS_SAMPLE && P.sample == P.spp) {
                 /* ray.cpp:1428 */
                 V3 o = divs(P.color, (float)P.spp);
                 uint32_t px = P.pxy & 0xffffu, py = P.pxy >> 16;
@@ -552,8 +510,53 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderView &rv, PathState &P, 
                 } else {
                     P.ps = PS_PIXEL;
                 }
-                continue;
             }
+            if (P.ps == PS_NEED_JOB) {
+                unsigned long long j = ORT_NEXT_JOB(rv.next_job);
+                if (j >= rv.job_count) { P.ps = PS_DONE; break; }
+                if (rv.mode == JOBS_EXPLICIT) {
+                    ort_tile_job jb = rv.jobs[j];
+                    P.job_index = (uint32_t)j;
+                    P.jxx = (uint32_t)jb.x0 | ((uint32_t)jb.x1 << 16);
+                    P.jyp = (uint32_t)jb.y1;
+                    P.pxy = (uint32_t)jb.x0 | ((uint32_t)jb.y0 << 16);
+                    P.rng = jb.rng_state; P.spp = jb.spp;
+                    if (jb.x1 <= jb.x0 || jb.y1 <= jb.y0) { /* empty rect: the reference loops zero times */
+                        if (rv.final_states) rv.final_states[P.job_index] = P.rng;
+                        continue;
+                    }
+                } else {
+                    /* implicit job space: [chunk k][my 8x8 block b][pixel-in-block p] */
+                    unsigned long long per_chunk = (unsigned long long)rv.my_blocks * 64ull;
+                    uint32_t k = (uint32_t)(j / per_chunk);
+                    uint32_t rem = (uint32_t)(j % per_chunk);
+                    uint32_t blk = rv.shard_index + (rem >> 6) * rv.shard_count;
+                    uint32_t pin = rem & 63u;
+                    int x = (int)((blk % rv.blocks_w) * 8u + (pin & 7u));
+                    int y = (int)((blk / rv.blocks_w) * 8u + (pin >> 3));
+                    if (x < rv.x0 || x >= rv.x1 || y < rv.y0 || y >= rv.y1) continue;
+                    uint32_t pix = (uint32_t)(y * rv.W + x);
+                    P.jxx = (uint32_t)x | ((uint32_t)(x + 1) << 16);
+                    P.pxy = (uint32_t)x | ((uint32_t)y << 16);
+                    if (rv.mode == JOBS_PIXEL) {
+                        P.rng = job_seed(rv.seed, pix);
+                        P.spp = rv.spp;
+                        P.jyp = (uint32_t)(y + 1);
+                    } else {
+                        P.rng = job_seed(rv.seed, k * (uint32_t)(rv.W * rv.H) + pix);
+                        P.spp = rv.chunk;
+                        P.jyp = (uint32_t)(y + 1) | (k << 16);
+                    }
+                }
+                P.ps = PS_PIXEL;
+            }
+            if (P.ps == PS_PIXEL) {
+                ORT_SIM_PIXEL_HOOK((int)(P.pxy & 0xffffu), (int)(P.pxy >> 16), P.rng);
+                P.color = mk(0, 0, 0); /* ray.cpp:1211 */
+                P.sample = 0;
+                P.ps = PS_SAMPLE;
+            }
+            if (P.sample == P.spp) continue; /* spp == 0: the reference's sample loop runs zero times */
             /* ray.cpp:1215-1221: point on the focal plane through the pixel centre (recomputed per
                sample instead of held in registers: same expressions, same bits) */
             float fx = (2.0f * (int)(P.pxy & 0xffffu) / (float)rv.W) - 1.0f; /* i32 -> f32, as the reference's x, y */
