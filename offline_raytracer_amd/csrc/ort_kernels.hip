@@ -61,6 +61,7 @@ struct SceneView {
     uint32_t *bfs_locks;
     uint32_t bfs_queue_cap, bfs_queue_count;
     unsigned long long *fallback_counters; /* [0] rays re-cast exactly, [1] queue overflows (cannot happen: kept as a tripwire) */
+    unsigned long long *util; /* diagnostics (ORT_DEBUG_UTIL=1, counters build): per-phase wave-iteration and active-lane sums */
     uint32_t force_fallback_mask; /* tests (ORT_DEBUG_FORCE_FALLBACK): also re-cast rays with (bits(dir.x) & mask) == 0; ~0u = off */
 };
 
@@ -75,6 +76,8 @@ struct RenderView {
     uint32_t seed, spp, chunk, nchunks;
     float rr;
     int refill_below; /* leave the traversal loop when fewer lanes than this are still tracing */
+    int descend_below; /* leave the descend loop (to process the leaves already reached, and perhaps refill) when
+                          fewer lanes than this are still walking interior nodes */
     uint32_t shard_index, shard_count, blocks_w, my_blocks;
     float *out;      /* W*H*3 */
     float *partial;  /* nchunks * W*H*3 (CHUNK) */
@@ -140,6 +143,7 @@ enum : int { PS_NEED_JOB = 0, PS_PIXEL = 1, PS_SAMPLE = 2, PS_HIT = 3, PS_DONE =
 #define ORT_FENCE()
 #define ORT_FFS64(m) __builtin_ffsll((long long)(m))
 #define ORT_LANE() 0
+#define ORT_UTIL(sv, k, pred)
 #ifndef ORT_SIM_PIXEL_HOOK
 #define ORT_SIM_PIXEL_HOOK(x, y, rng)
 #endif
@@ -158,6 +162,17 @@ enum : int { PS_NEED_JOB = 0, PS_PIXEL = 1, PS_SAMPLE = 2, PS_HIT = 3, PS_DONE =
 #define ORT_FENCE() __threadfence()
 #define ORT_FFS64(m) __ffsll((unsigned long long)(m))
 #define ORT_LANE() ((int)__lane_id())
+/* lane-utilisation probe: event k happened in this wave with popc(pred) lanes taking part */
+#define ORT_UTIL(sv, k, pred)                                                                        \
+    do {                                                                                             \
+        if (COUNTERS && (sv).util) {                                                                 \
+            unsigned long long m_ = __ballot(pred);                                                  \
+            if (m_ && (int)__lane_id() == __ffsll(m_) - 1) {                                         \
+                atomicAdd((sv).util + 2 * (k), 1ull);                                                \
+                atomicAdd((sv).util + 2 * (k) + 1, (unsigned long long)__popcll(m_));                \
+            }                                                                                        \
+        }                                                                                            \
+    } while (0)
 #endif
 
 
@@ -435,6 +450,7 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderView &rv, PathState &P, 
     const float aperture = 0.1f;                                /* ray.cpp:1199 */
 
     while (P.ps != PS_DONE) {
+        ORT_UTIL(sv, 5, true);
         bool bounce = false;
         float angle = 0.0f;
         BrdfDraw draw;
@@ -484,6 +500,7 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderView &rv, PathState &P, 
                     uint32_t li = P.rng % sv.light_count;
                     if (sv.light_is_sphere[li]) { rng_step(P.rng); rng_step(P.rng); rng_step(P.rng); rng_step(P.rng); }
                 }
+                ORT_UTIL(sv, 6, true);
                 draw = sample_brdf_draw(P.rng, kRoughness, m);
                 angle = draw.phi;
             } else {
@@ -568,6 +585,7 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderView &rv, PathState &P, 
         /* lanes that bounce and lanes that start a new camera sample both need cos/sin of one angle
            (lobe azimuth / aperture angle): the double-precision evaluation happens here once,
            converged, instead of once in each branch (same operand, same bits) */
+        ORT_UTIL(sv, 7, true);
         float cs = ort_cosf(angle), sn = ort_sinf(angle);
         if (bounce) {
             bool is_trans;
@@ -617,17 +635,19 @@ ORT_D void begin_ray(const PathState &P, Trav &T, HitState &h) {
  * refill_below lanes of the wave are still traversing (the caller resumes later: all state is in T/h). */
 template <bool COUNTERS, int LDS_ENTRIES, int BLOCK>
 ORT_D bool traverse(const SceneView &sv, V3 org, V3 dir, Trav &T, HitState &h, uint32_t *lds_stack, uint32_t *spill, int tid,
-                    int refill_below, Counters &c) {
+                    int refill_below, int descend_below, Counters &c) {
     bool tracing = true;
     uint32_t cur = T.cur;
     int sp = T.sp;
     const V3 inv_d = T.inv_d;
     while (tracing) {
+        ORT_UTIL(sv, 2, true);
 #if ORT_TRAV_WHILEWHILE
         while (!(cur & LEAF_BIT)) {
 #else
         if (!(cur & LEAF_BIT)) {
 #endif
+            ORT_UTIL(sv, 0, true);
             const float4 *np = sv.nodes + 4u * (cur & NODE_INDEX_MASK);
             float4 a = np[0], b = np[1], cc = np[2], d = np[3];
             uint32_t c0 = om_f32_bits(d.x), c1 = om_f32_bits(d.y);
@@ -663,14 +683,22 @@ ORT_D bool traverse(const SceneView &sv, V3 org, V3 dir, Trav &T, HitState &h, u
                 sp--;
                 cur = (sp < LDS_ENTRIES) ? lds_stack[sp * BLOCK + tid] : spill[sp - LDS_ENTRIES];
             }
+#if ORT_TRAV_WHILEWHILE
+            /* the stragglers of the descend loop would keep the rest of the wave waiting: break out
+               and come back for them (their cur / sp carry over) */
+            if (ORT_POPC64(ORT_BALLOT(true)) < descend_below) break;
+#endif
         }
 #if ORT_TRAV_WHILEWHILE
-        if (cur == kTraversalDone) {
+        if (!(cur & LEAF_BIT)) {
+            /* still on an interior node after the early exit above: nothing to do this round */
+        } else if (cur == kTraversalDone) {
 #else
         else if (cur == kTraversalDone) {
 #endif
             tracing = false;
         } else {
+            ORT_UTIL(sv, 1, true);
             uint32_t kind = (cur >> 28) & 7u, count = ((cur >> 24) & 15u) + 1u, first = cur & 0x00ffffffu;
             for (uint32_t i = 0; i < count; ++i)
                 test_prim<COUNTERS, false>(sv, kind, first + i, org, dir, inv_d, h.best_t, h.hit_n, h.hit_prim, h.phantom_t, c.tris, c.analytic);
@@ -711,6 +739,8 @@ ORT_D void pt_lane(const SceneView &sv, const RenderView &rv, uint32_t *lds_stac
     bool tracing = false;
     for (;;) {
         if (!tracing) {
+            ORT_UTIL(sv, 3, true);
+            ORT_UTIL(sv, 4, P.ps == PS_HIT);
             if (P.ps == PS_HIT) resolve_hit<COUNTERS>(sv, P.org, P.dir, T.inv_d, lane_id, h, c);
             tracing = produce_ray<COUNTERS, DIFFUSE>(sv, rv, P, h, c);
             if (tracing) {
@@ -719,7 +749,7 @@ ORT_D void pt_lane(const SceneView &sv, const RenderView &rv, uint32_t *lds_stac
             }
         }
         if (ORT_BALLOT(P.ps != PS_DONE) == 0ull) break;
-        if (tracing) tracing = traverse<COUNTERS, kLdsStack, kBlock>(sv, P.org, P.dir, T, h, lds_stack, spill, tid, rv.refill_below, c);
+        if (tracing) tracing = traverse<COUNTERS, kLdsStack, kBlock>(sv, P.org, P.dir, T, h, lds_stack, spill, tid, rv.refill_below, rv.descend_below, c);
     }
     flush_counters(rv, c, COUNTERS);
 }
@@ -776,7 +806,7 @@ ORT_D void wf_trace_slot(const SceneView &sv, const WfView &wf, uint32_t i, uint
     HitState h;
     Trav T;
     begin_ray(P, T, h);
-    traverse<COUNTERS, kWfLdsStack, kBlock>(sv, P.org, P.dir, T, h, lds_stack, spill, tid, 0, c);
+    traverse<COUNTERS, kWfLdsStack, kBlock>(sv, P.org, P.dir, T, h, lds_stack, spill, tid, 0, 0, c);
     resolve_hit<COUNTERS>(sv, P.org, P.dir, T.inv_d, lane_id, h, c);
     wf.hit0[i] = make_float4(h.best_t, h.hit_n.x, h.hit_n.y, h.hit_n.z);
     wf.hitp[i] = h.hit_prim;
@@ -1014,8 +1044,8 @@ int device_upload(Scene *scene, int device, std::string *err) {
     if ((rc = upload_vec(rt.sphere_order, &d->sphere_order, err))) return rc;
     if ((rc = upload_vec(rt.box_order, &d->box_order, err))) return rc;
     if ((rc = upload_vec(rt.cyl_order, &d->cyl_order, err))) return rc;
-    ORT_HIP(hipMalloc((void **)&d->ctrl, 8 * sizeof(unsigned long long)));
-    ORT_HIP(hipMemset(d->ctrl, 0, 8 * sizeof(unsigned long long)));
+    ORT_HIP(hipMalloc((void **)&d->ctrl, 32 * sizeof(unsigned long long)));
+    ORT_HIP(hipMemset(d->ctrl, 0, 32 * sizeof(unsigned long long)));
     ORT_HIP(hipEventCreate(&d->ev0));
     ORT_HIP(hipEventCreate(&d->ev1));
     hipDeviceProp_t prop;
@@ -1150,6 +1180,8 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
     const char *ff = getenv("ORT_DEBUG_FORCE_FALLBACK");
     sv.force_fallback_mask = ff ? (uint32_t)strtoul(ff, nullptr, 0) : 0xffffffffu;
     sv.fallback_counters = d->ctrl + 6;
+    const bool want_util = getenv("ORT_DEBUG_UTIL") != nullptr; /* developer diagnostics, counters build only */
+    sv.util = want_util ? d->ctrl + 8 : nullptr;
     ort_camera cam;
     camera_basis(*scene, p->width, p->height, &cam);
     memcpy(sv.cam, &cam, sizeof(cam));
@@ -1164,6 +1196,10 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
         rv.refill_below = e ? atoi(e) : 12; /* tuned on MI355X: profiles/r01_tuning.md */
         if (rv.refill_below < 1) rv.refill_below = 1;
         if (rv.refill_below > 64) rv.refill_below = 64;
+        e = getenv("ORT_DESCEND_BELOW");
+        rv.descend_below = e ? atoi(e) : 8; /* 0 -> 8: +10 % (profiles/r01_tuning.md) */
+        if (rv.descend_below < 0) rv.descend_below = 0;
+        if (rv.descend_below > 64) rv.descend_below = 64;
     }
     rv.next_job = d->ctrl;
     rv.counters = d->ctrl + 1;
@@ -1197,7 +1233,7 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
     }
 
     const bool counters = (p->flags & ORT_RENDER_COUNTERS) != 0;
-    ORT_HIP(hipMemsetAsync(d->ctrl, 0, 8 * sizeof(unsigned long long), stream));
+    ORT_HIP(hipMemsetAsync(d->ctrl, 0, 32 * sizeof(unsigned long long), stream));
     /* persistent grid: 4 blocks of 256 lanes per CU, never more lanes than jobs */
     unsigned long long lanes_wanted = rv.job_count;
     unsigned int max_blocks = d->max_blocks;
@@ -1246,6 +1282,15 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
             ORT_HIP(hipMemcpy(c, d->ctrl + 1, sizeof(c), hipMemcpyDeviceToHost));
             stats->paths = c[0]; stats->rays = c[1]; stats->node_tests = c[2]; stats->tri_tests = c[3]; stats->analytic_tests = c[4];
             stats->fallback_rays = c[5];
+            if (want_util) {
+                static const char *names[8] = {"node visit", "leaf visit", "traverse outer iteration", "shade call", "  of which lanes with a finished ray",
+                                               "produce_ray pass", "  bounce draw", "  sin/cos + ray setup"};
+                unsigned long long u[16];
+                ORT_HIP(hipMemcpy(u, d->ctrl + 8, sizeof(u), hipMemcpyDeviceToHost));
+                for (int k = 0; k < 8; ++k)
+                    fprintf(stderr, "util %-40s wave-events %14llu  mean active lanes %6.2f\n", names[k], u[2 * k],
+                            u[2 * k] ? (double)u[2 * k + 1] / (double)u[2 * k] : 0.0);
+            }
         }
     }
     return ORT_OK;

@@ -67,6 +67,7 @@ int main(int argc, char **argv) {
     rv.W = W; rv.H = H; rv.x0 = 0; rv.y0 = 0; rv.x1 = W; rv.y1 = H;
     rv.seed = seed; rv.spp = spp; rv.chunk = chunk; rv.rr = 0.8f;
     rv.refill_below = 12;
+    rv.descend_below = getenv("SIM_DESCEND_BELOW") ? atoi(getenv("SIM_DESCEND_BELOW")) : 8;
     rv.out = out.data(); rv.next_job = ctrl; rv.counters = ctrl + 1;
     sv.fallback_counters = ctrl + 6;
     rv.shard_count = argc > 11 ? (uint32_t)atoi(argv[11]) : 1; rv.shard_index = argc > 11 ? (uint32_t)atoi(argv[10]) : 0;

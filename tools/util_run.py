@@ -1,0 +1,16 @@
+"""Developer script: lane-utilisation probes of the counters build (ORT_DEBUG_UTIL=1 prints to stderr).
+usage: python3 tools/util_run.py [scene] [W] [H] [spp] [chunk]"""
+import os, sys
+os.environ["ORT_DEBUG_UTIL"] = "1"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from offline_raytracer_amd import api
+a = sys.argv[1:]
+name = a[0] if len(a) > 0 else "c3_bunny_room"
+W = int(a[1]) if len(a) > 1 else 1920
+H = int(a[2]) if len(a) > 2 else 1080
+spp = int(a[3]) if len(a) > 3 else 16
+chunk = int(a[4]) if len(a) > 4 else 16
+scene = api.Scene.load_scn(os.path.join(ROOT, "data", name + ".scn")).commit().upload(0)
+img, st = scene.render(W, H, spp, 12345, "chunk", chunk=chunk, counters=True)
+print(name, st)
