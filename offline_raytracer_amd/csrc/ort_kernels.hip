@@ -1197,7 +1197,12 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
         if (rv.refill_below < 1) rv.refill_below = 1;
         if (rv.refill_below > 64) rv.refill_below = 64;
         e = getenv("ORT_DESCEND_BELOW");
-        rv.descend_below = e ? atoi(e) : 8; /* 0 -> 8: +10 % (profiles/r01_tuning.md) */
+        /* 8 is worth +10 % while the fast tree is cache-resident (bunny room: 6 MB).  On the 1M-triangle
+           scene (86 MB, 60 % L2 hits, latency-bound) it halves the throughput of long launches -- L2 read
+           latency 270 -> 690 cycles at equal request counts, not understood (profiles/r01_tuning.md) --
+           so trees that cannot stay in the 8 x 4 MB of L2 keep the plain while-while loop */
+        const size_t fast_tree_bytes = scene->tree.nodes.size() * sizeof(DevNode) + scene->tree.tris.size() * sizeof(DevTri);
+        rv.descend_below = e ? atoi(e) : (fast_tree_bytes <= (size_t)(16u << 20) ? 8 : 0);
         if (rv.descend_below < 0) rv.descend_below = 0;
         if (rv.descend_below > 64) rv.descend_below = 64;
     }

@@ -11,6 +11,13 @@ W = int(a[1]) if len(a) > 1 else 1920
 H = int(a[2]) if len(a) > 2 else 1080
 spp = int(a[3]) if len(a) > 3 else 16
 chunk = int(a[4]) if len(a) > 4 else 16
-scene = api.Scene.load_scn(os.path.join(ROOT, "data", name + ".scn")).commit().upload(0)
+if name.startswith("c5:"):  # generated height field, e.g. c5:708
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_heightfield
+    path, _, _ = make_heightfield.write_scene(int(name[3:]), tempfile.mkdtemp(prefix="c5_"))
+else:
+    path = os.path.join(ROOT, "data", name + ".scn")
+scene = api.Scene.load_scn(path).commit().upload(0)
 img, st = scene.render(W, H, spp, 12345, "chunk", chunk=chunk, counters=True)
 print(name, st)
