@@ -402,11 +402,14 @@ void place_mesh(HostMesh *mesh, const float translate[3], float scale, float deg
     }
 }
 
-/* text after the first '.' of the whole path, compared by prefix (parser.cpp:91-108,
-   macos_main.mm:351-366) */
+/* The reference takes the text after the FIRST '.' of the whole path (get_extension,
+   parser.cpp:91-108, used at macos_main.mm:351-366; its own note: "does not work if there was a
+   directory with ."), compared by prefix.  Here: after the last '.' of the file name -- the same
+   answer wherever the reference works, and a defined one for "../data/x.obj" or "/tmp/a.b/x.ply". */
 bool extension_is(const std::string &path, const char *ext) {
-    size_t dot = path.find('.');
-    if (dot == std::string::npos) return false;
+    size_t slash = path.find_last_of('/');
+    size_t dot = path.find_last_of('.');
+    if (dot == std::string::npos || (slash != std::string::npos && dot < slash)) return false;
     const char *p = path.c_str() + dot + 1;
     while (*p && *ext) {
         if (*p != *ext) return false;

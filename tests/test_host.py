@@ -225,3 +225,38 @@ def test_hdr_file_layout(api, oracle, tmp_path):
     assert len(a) == len(header) + 5 * 7 * 4  # the showcase files obey the same size rule: 50 + 1280*720*4
     first = np.frombuffer(a[len(header):len(header) + 4], "<u4")[0]
     assert first == api.rgbe(*img[4, 0])
+
+
+# ---- the command-line driver (replacement for main(), macos_main.mm:289-710) -------------------------
+CLI = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "offline_raytracer_amd", "bin", "ort_render")
+
+
+def test_cli_usage_and_failures(api, tmp_path):
+    """argument errors exit 2; a missing scene exits 1 with the library's message; on a machine without a
+    HIP device the render step fails loudly instead of falling back to anything"""
+    import subprocess
+    assert os.path.exists(CLI), "bin/ort_render is built by the csrc Makefile"
+    assert subprocess.run([CLI], capture_output=True).returncode == 2
+    assert subprocess.run([CLI, "--scene"], capture_output=True).returncode == 2
+    r = subprocess.run([CLI, "--scene", str(tmp_path / "nope.scn")], capture_output=True, text=True)
+    assert r.returncode == 1 and "load failed" in r.stderr
+    if api.device_count() == 0:
+        r = subprocess.run([CLI, "--scene", os.path.join(DATA, "c2_analytic.scn"), "--width", "16", "--height", "8", "--spp", "1",
+                            "--out", str(tmp_path / "x.hdr")], capture_output=True, text=True)
+        assert r.returncode != 0 and not os.path.exists(tmp_path / "x.hdr")
+        assert "device" in r.stderr.lower()
+
+
+def test_mesh_paths_with_dotted_directories(api, tmp_path):
+    """the reference's get_extension stops at the first '.' of the whole path (parser.cpp:91-108: "does not
+    work if there was a directory with ."); the product uses the file name's last '.'"""
+    import shutil
+    d = tmp_path / "scene.v1.dir"
+    d.mkdir()
+    for f in ("c4_dwarf_room.scn", "dwarf.obj"):
+        shutil.copy(os.path.join(DATA, f), d)
+    assert api.Scene.load_scn(str(d / "c4_dwarf_room.scn")).info().triangle_count == 1896
+    assert api.Scene.load_scn(os.path.join(DATA, "..", "data", "c3_bunny_room.scn")).info().triangle_count == 69451
+    (d / "bad.scn").write_text("brdf 0.5 0.5 0.5 0.0 0.0 0.0 10\nmesh dwarf.xyz 0.0 0.0 0.0 1.0\n")
+    with pytest.raises(api.OrtError):
+        api.Scene.load_scn(str(d / "bad.scn"))
