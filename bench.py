@@ -176,9 +176,12 @@ def main():
     my_paths = paths_per_step / world  # per launch on this rank (blocks are dealt round-robin)
     k_ms = sum(kernel_ms) / len(kernel_ms)
     achieved = bytes_per_path * my_paths / (k_ms * 1e-3) / 1e9
+    # measured HBM bytes per launch come from a separate rocprofv3 --pmc run of THIS step (the profiler
+    # cannot be attached from inside): only quoted when the configuration is the profiled one
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(tpath):
+    profiled = (world == 1 and args.scene == "c3_bunny_room" and (W, H, args.spp, args.chunk) == (1920, 1080, 1024, 64))
+    if profiled and os.path.exists(tpath):
         try:
             traffic = json.load(open(tpath)).get("bytes_per_launch")
         except Exception:
