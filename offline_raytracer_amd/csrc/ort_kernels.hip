@@ -681,7 +681,10 @@ ORT_D bool traverse(const SceneView &sv, V3 org, V3 dir, Trav &T, HitState &h, u
                 cur = kTraversalDone;
             } else {
                 sp--;
-                cur = (sp < LDS_ENTRIES) ? lds_stack[sp * BLOCK + tid] : spill[sp - LDS_ENTRIES];
+                /* two real loads behind a branch (the volatile keeps the compiler from merging them into one
+                   flat_load of a selected generic pointer): the LDS side becomes a plain ds_read */
+                if (sp < LDS_ENTRIES) cur = lds_stack[sp * BLOCK + tid];
+                else cur = ((volatile uint32_t *)spill)[sp - LDS_ENTRIES];
             }
 #if ORT_TRAV_WHILEWHILE
             /* the stragglers of the descend loop would keep the rest of the wave waiting: break out
@@ -707,7 +710,10 @@ ORT_D bool traverse(const SceneView &sv, V3 org, V3 dir, Trav &T, HitState &h, u
                 tracing = false;
             } else {
                 sp--;
-                cur = (sp < LDS_ENTRIES) ? lds_stack[sp * BLOCK + tid] : spill[sp - LDS_ENTRIES];
+                /* two real loads behind a branch (the volatile keeps the compiler from merging them into one
+                   flat_load of a selected generic pointer): the LDS side becomes a plain ds_read */
+                if (sp < LDS_ENTRIES) cur = lds_stack[sp * BLOCK + tid];
+                else cur = ((volatile uint32_t *)spill)[sp - LDS_ENTRIES];
             }
         }
         /* when most of the wave has finished its ray, let the finished lanes shade and refill */
