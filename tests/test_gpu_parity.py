@@ -298,6 +298,66 @@ def test_no_mesh_and_single_primitive(api, oracle):
     s.close()
 
 
+def _degenerate_scene(api, variant):
+    """closed room plus geometry chosen to hit ties and degenerate branches"""
+    mats = np.zeros(7, api.MATERIAL_DTYPE)
+    mats["diffuse"][1] = (0.7, 0.7, 0.7); mats["diffuse"][2] = (0.8, 0.2, 0.2); mats["diffuse"][3] = (0.2, 0.2, 0.8)
+    mats["specular"][4, :3] = 1
+    mats["transmission"][5] = 1; mats["ior"][5] = 1.5
+    mats["is_light"][6] = 1; mats["emit"][6] = (4, 4, 4)
+    mats["ior"][1:5] = 1.0
+    room = [((-4, -4, -0.2), (4, 4, 0)), ((-4, -4, 5), (4, 4, 5.2)), ((-4.2, -4, -0.2), (-4, 4, 5.2)),
+            ((4, -4, -0.2), (4.2, 4, 5.2)), ((-4, -4.2, -0.2), (4, -4, 5.2)), ((-4, 4, -0.2), (4, 4.2, 5.2))]
+    boxes = [(lo, hi, 1) for lo, hi in room]
+    spheres = [((0, 0, 4.2), 0.7, 6)]
+    cyls = []
+    verts, idx = [], []
+    if variant == 0:
+        # coincident boxes with different materials (bit-equal t: first tested wins), a box face in the floor plane
+        boxes += [((-1, -1, 0), (1, 1, 1), 2), ((-1, -1, 0), (1, 1, 1), 3), ((1, -1, 0), (2, 1, 1), 3), ((-0.5, -0.5, 1), (0.5, 0.5, 1.5), 4)]
+        # coincident spheres, concentric spheres (glass shell around a diffuse core), sphere touching a box face
+        spheres += [((2, 2, 1), 0.5, 2), ((2, 2, 1), 0.5, 3), ((-2, 2, 1), 0.8, 5), ((-2, 2, 1), 0.4, 2), ((0, -2.5, 0.5), 0.5, 4)]
+    elif variant == 1:
+        # zero-area and duplicated triangles, a quad as two fan triangles plus its mirror image (same plane, opposite winding)
+        quad = [(-1, -1, 1), (1, -1, 1), (1, 1, 1), (-1, 1, 1)]
+        verts += quad + quad[::-1] + [(0, 0, 2), (0, 0, 2), (0, 0, 2)] + [(2, 0, 0.5), (3, 0, 0.5), (4, 0, 0.5)]
+        idx += [0, 1, 2, 0, 2, 3, 4, 5, 6, 4, 6, 7, 8, 9, 10, 11, 12, 13, 0, 1, 2]
+        cyls += [((-2, -2, 0), (0, 0, 2), 0.3, 2), ((-2, -2, 0), (0, 0, 2), 0.3, 3), ((2, -2, 1), (0, 0, -1), 0.2, 4),
+                 ((0, 3, 1), (2, 0, 0), 1e-3, 2)]
+    else:
+        # shapes poking through the walls, a sphere bigger than the room's half, a cylinder along a wall plane
+        spheres += [((4, 0, 2), 1.0, 2), ((0, 0, 0), 1.0, 5), ((-3.5, -3.5, 0.5), 0.5, 4)]
+        boxes += [((3.5, 3.5, 0), (4.5, 4.5, 6), 3)]
+        cyls += [((-4, -3, 1), (0, 6, 0), 0.25, 2), ((0, 0, 0), (0, 0, 5), 0.1, 4)]
+    sph = np.zeros(len(spheres), api.SPHERE_DTYPE)
+    for i, v in enumerate(spheres):
+        sph[i] = v
+    box = np.zeros(len(boxes), api.BOX_DTYPE)
+    for i, v in enumerate(boxes):
+        box[i] = v
+    cyl = np.zeros(len(cyls), api.CYLINDER_DTYPE)
+    for i, v in enumerate(cyls):
+        cyl[i] = v
+    lights = np.array([(2, i) for i in range(len(cyls))] + [(1, 0)], api.LIGHT_DTYPE)
+    meshes = [dict(vertices=np.array(verts, "<f4"), indices=np.array(idx, "<u4"), mat=2)] if verts else []
+    q = np.array([0.279589, 0.480987, 0.718247, 0.416981], "<f4")
+    return api.Scene.from_arrays(mats, sph, box, cyl, lights, meshes, camera_p=(3.3, 2.0, 2.6), camera_quat_xyzw=q,
+                                 camera_height_ratio=0.3, screen=(64, 48))
+
+
+@pytest.mark.parametrize("variant", range(3))
+def test_degenerate_geometry(api, oracle, variant):
+    """coincident / concentric / touching shapes (ties in t), zero-area and duplicated triangles, a quad and its
+    mirror image, needle cylinders, shapes that poke through the room: same bits as the oracle"""
+    scene = _degenerate_scene(api, variant).commit().upload(0)
+    w, h, spp = 64, 48, 16
+    img, st = scene.render(w, h, spp, 4000 + variant, "chunk", chunk=4, counters=True)
+    ref, ost = oracle.OracleScene(scene.flatten(w, h), with_reference_csg=False).render(w, h, spp, 4000 + variant, "chunk", chunk=4, threads=16)
+    assert st["rays"] == ost["rays"]
+    assert_bits_equal(img, ref, "degenerate scene %d" % variant)
+    scene.close()
+
+
 def test_open_scene_terminates(api):
     """primary misses are undefined behaviour in the reference; defined here as
     'the path ends with zero radiance'.  Must not hang or fault."""
