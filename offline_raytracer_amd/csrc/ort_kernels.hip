@@ -192,7 +192,7 @@ ORT_D uint32_t prim_order(const SceneView &sv, uint32_t kind, uint32_t slot) {
    accept when hit_t >= 1e-6 and strictly closer than the best so far */
 template <bool COUNTERS, bool EXACT_ORDER>
 ORT_D void test_prim(const SceneView &sv, uint32_t kind, uint32_t slot, V3 org, V3 dir, V3 inv_d, float &best_t, V3 &hit_n,
-                     uint32_t &hit_prim, float &phantom_t, unsigned long long &c_tris, unsigned long long &c_analytic) {
+                     uint32_t &hit_prim, float &phantom_t, float &runner_t, unsigned long long &c_tris, unsigned long long &c_analytic) {
     float t;
     V3 n = mk(0, 0, 0);
     bool tangent = false;
@@ -228,6 +228,9 @@ ORT_D void test_prim(const SceneView &sv, uint32_t kind, uint32_t slot, V3 org, 
            keeps whichever it tested first */
         take = prim_order(sv, kind, slot) < prim_order(sv, hit_prim >> 28, hit_prim & 0x00ffffffu);
     }
+    /* the nearest hit that does NOT win (fast traversal only): resolve_hit needs to know that nothing
+       else lies between the winner and the entry of its node boxes */
+    if (!EXACT_ORDER && t >= kHitTMin) runner_t = fminf(runner_t, take ? best_t : t);
     if (take) {
         best_t = t;
         hit_n = n;
@@ -235,18 +238,28 @@ ORT_D void test_prim(const SceneView &sv, uint32_t kind, uint32_t slot, V3 org, 
     }
 }
 
-/* the reference's child test without its "closer than best" clause (ray.cpp:788-803):
-   origin inside the box (half-open), or the slab test enters at t >= 1e-6 */
-ORT_D bool ref_node_admits(V3 lo, V3 hi, V3 org, V3 inv_d) {
+/* the reference's child test (ray.cpp:788-803) as far as it can be decided after the fact: origin
+   inside the box (half-open), or the slab test enters at 1e-6 <= t <= t_hit, t_hit being the distance of
+   the winner W of the fast traversal (the minimum over ALL primitives, ties to the lower test rank).
+   The reference's clause is "t < best at that moment"; every primitive it tested before this node has a
+   lower rank than W, hence a strictly larger distance, so best > t_hit and an entry at t <= t_hit
+   passes.  An entry BEYOND t_hit (a hit in front of its own node box: cylinder and sphere boxes are
+   not conservative to the last ulp, and a flat box around an axis-aligned triangle rounds either way)
+   passes or not depending on what was found earlier -- unless nothing else CAN have been found below it:
+   t_other is the nearest other hit (runner-up or phantom), exact within 2e-4 of t_hit because the fast
+   traversal tests everything in that window; an entry below t_other (and inside the window) is below
+   any best the reference can have held.  Otherwise undecidable here: the caller re-casts exactly. */
+ORT_D bool ref_node_admits(V3 lo, V3 hi, V3 org, V3 inv_d, float t_hit, float t_other) {
     if ((org.x >= lo.x && org.x < hi.x) && (org.y >= lo.y && org.y < hi.y) && (org.z >= lo.z && org.z < hi.z)) return true;
-    return hit_aab_t(lo, hi, org, inv_d) >= kHitTMin;
+    const float t = hit_aab_t(lo, hi, org, inv_d);
+    return t >= kHitTMin && (t <= t_hit || (t < t_other && t < t_hit * 1.0001f));
 }
 
 /* would the reference have reached this primitive?  Every node box on the way down must admit the
    ray (origin inside, half-open; or entered at t >= 1e-6).  Entries run from the primitive's own node
    (entry 0, the smallest box) up to the root's child.  chain_admits_full tests them all, four at a
    time so the (divergent, L2-latency-bound) loads overlap. */
-ORT_D bool chain_admits_full(const SceneView &sv, uint32_t first, uint32_t len, V3 org, V3 inv_d) {
+ORT_D bool chain_admits_full(const SceneView &sv, uint32_t first, uint32_t len, V3 org, V3 inv_d, float t_hit, float t_other) {
     bool ok = true;
     for (uint32_t base = 0; base < len; base += 4u) {
         float4 lo[4], hi[4];
@@ -259,7 +272,7 @@ ORT_D bool chain_admits_full(const SceneView &sv, uint32_t first, uint32_t len, 
         }
 #pragma unroll
         for (uint32_t k = 0; k < 4u; ++k)
-            ok = ok && ref_node_admits(mk(lo[k].x, lo[k].y, lo[k].z), mk(hi[k].x, hi[k].y, hi[k].z), org, inv_d);
+            ok = ok && ref_node_admits(mk(lo[k].x, lo[k].y, lo[k].z), mk(hi[k].x, hi[k].y, hi[k].z), org, inv_d, t_hit, t_other);
         if (!ok) break;
     }
     return ok;
@@ -281,7 +294,7 @@ constexpr uint32_t kChainNested = 0x08000000u;
 #if defined(ORT_HOST_SIM) && defined(ORT_CHAIN_CROSSCHECK)
 static unsigned long long g_chain_crosschecks = 0;
 #endif
-ORT_D bool chain_admits(const SceneView &sv, uint32_t prim, V3 org, V3 inv_d) {
+ORT_D bool chain_admits(const SceneView &sv, uint32_t prim, V3 org, V3 inv_d, float t_hit, float t_other) {
     uint32_t kind = prim >> 28, slot = prim & 0x00ffffffu;
     uint32_t word = (kind == PRIM_TRI) ? sv.tri_chain[slot]
                   : (kind == PRIM_SPHERE) ? sv.sphere_chain[slot]
@@ -290,7 +303,7 @@ ORT_D bool chain_admits(const SceneView &sv, uint32_t prim, V3 org, V3 inv_d) {
     if (len == 0u) return true;
     const bool finite = (om_f32_bits(inv_d.x) & 0x7fffffffu) < 0x7f800000u && (om_f32_bits(inv_d.y) & 0x7fffffffu) < 0x7f800000u &&
                         (om_f32_bits(inv_d.z) & 0x7fffffffu) < 0x7f800000u;
-    if (!(word & kChainNested) || !finite) return chain_admits_full(sv, first, len, org, inv_d);
+    if (!(word & kChainNested) || !finite) return chain_admits_full(sv, first, len, org, inv_d, t_hit, t_other);
     const float4 dlo = sv.chain_boxes[2u * first], dhi = sv.chain_boxes[2u * first + 1u];
     float4 jlo = dlo, jhi = dhi;
     bool found = false;
@@ -313,10 +326,11 @@ ORT_D bool chain_admits(const SceneView &sv, uint32_t prim, V3 org, V3 inv_d) {
         }
     }
     /* !found: the origin is inside every box of the chain */
+    /* the entry distance only grows down the chain: the upper bound needs checking at the leaf box alone */
     const bool admits = !found || (hit_aab_t(mk(jlo.x, jlo.y, jlo.z), mk(jhi.x, jhi.y, jhi.z), org, inv_d) >= kHitTMin &&
-                                   ref_node_admits(mk(dlo.x, dlo.y, dlo.z), mk(dhi.x, dhi.y, dhi.z), org, inv_d));
+                                   ref_node_admits(mk(dlo.x, dlo.y, dlo.z), mk(dhi.x, dhi.y, dhi.z), org, inv_d, t_hit, t_other));
 #if defined(ORT_HOST_SIM) && defined(ORT_CHAIN_CROSSCHECK) /* tools/host_sim: the shortcut against the full walk, every ray */
-    if (admits != chain_admits_full(sv, first, len, org, inv_d)) { fprintf(stderr, "chain shortcut disagrees with the full walk\n"); abort(); }
+    if (admits != chain_admits_full(sv, first, len, org, inv_d, t_hit, t_other)) { fprintf(stderr, "chain shortcut disagrees with the full walk\n"); abort(); }
     g_chain_crosschecks++;
 #endif
     return admits;
@@ -347,7 +361,7 @@ ORT_D bool ref_raycast_bfs(const SceneView &sv, V3 org, V3 dir, V3 inv_d, uint32
         uint32_t rec_first = om_f32_bits(b.w), rec_count = om_f32_bits(c.x);
         for (uint32_t r = 0; r < rec_count; ++r) {
             uint32_t rec = sv.ref_recs[rec_first + r];
-            test_prim<COUNTERS, true>(sv, rec >> 28, rec & 0x00ffffffu, org, dir, inv_d, best_t, hit_n, hit_prim, unused, c_tris, c_analytic);
+            test_prim<COUNTERS, true>(sv, rec >> 28, rec & 0x00ffffffu, org, dir, inv_d, best_t, hit_n, hit_prim, unused, unused, c_tris, c_analytic);
         }
         if (first_child >= 0) {
             for (uint32_t k = 0; k < 8u; ++k) {
@@ -402,6 +416,7 @@ struct HitState {
     V3 hit_n;
     uint32_t hit_prim = kNoPrim;
     float phantom_t = 0;
+    float runner_t = 0; /* nearest hit other than the winner, exact below best_t * 1.0002 (kCullSlack) */
 };
 
 ORT_D float *job_plane(const RenderView &rv, uint32_t plane) {
@@ -412,7 +427,7 @@ ORT_D float *job_plane(const RenderView &rv, uint32_t plane) {
    phantom tangent hit could have won, re-cast the ray exactly. */
 template <bool COUNTERS>
 ORT_D void resolve_hit(const SceneView &sv, V3 org, V3 dir, V3 inv_d, uint32_t lane_id, HitState &h, Counters &c) {
-    const bool need = (h.hit_prim != kNoPrim && !chain_admits(sv, h.hit_prim, org, inv_d)) || h.phantom_t <= h.best_t ||
+    const bool need = (h.hit_prim != kNoPrim && !chain_admits(sv, h.hit_prim, org, inv_d, h.best_t, fminf(h.runner_t, h.phantom_t))) || h.phantom_t <= h.best_t ||
                       (sv.force_fallback_mask != 0xffffffffu && (om_f32_bits(dir.x) & sv.force_fallback_mask) == 0u);
     /* Rare.  The lanes of a wave that need the re-cast take turns (wave-uniform loop over the ballot), so
        a wave never has more than one lane holding or waiting for a queue of the pool: a waiting lane can
@@ -623,6 +638,7 @@ ORT_D void begin_ray(const PathState &P, Trav &T, HitState &h) {
     h.hit_n = mk(0, 0, 0);
     h.hit_prim = kNoPrim;
     h.phantom_t = __builtin_inff(); /* none yet; compared with <= against best_t (<= FLT_MAX) */
+    h.runner_t = __builtin_inff();
 }
 
 /* Closest hit: interruptible ordered DFS, replaces raycast_bvh (ray.cpp:624-822) on the fast tree.
@@ -633,6 +649,11 @@ ORT_D void begin_ray(const PathState &P, Trav &T, HitState &h) {
  * conservative; fminf/fmaxf drop the NaN of 0 * inf, i.e. that axis is ignored.
  * Returns when this lane's ray is finished, or -- refill_below > 0 -- as soon as fewer than
  * refill_below lanes of the wave are still traversing (the caller resumes later: all state is in T/h). */
+/* a child is skipped only when its entry distance (less the slab test's rounding margin, 0.9999996)
+   is beyond best_t * 1.0002: every primitive hit within 2e-4 of the final winner is therefore tested,
+   which is what makes HitState::runner_t exact in that window */
+constexpr float kCullSlack = 0.9997996f; /* <= 0.9999996 / 1.0002 */
+
 template <bool COUNTERS, int LDS_ENTRIES, int BLOCK>
 ORT_D bool traverse(const SceneView &sv, V3 org, V3 dir, Trav &T, HitState &h, uint32_t *lds_stack, uint32_t *spill, int tid,
                     int refill_below, int descend_below, Counters &c) {
@@ -664,8 +685,8 @@ ORT_D bool traverse(const SceneView &sv, V3 org, V3 dir, Trav &T, HitState &h, u
             float n1 = fmaxf(fmaxf(fminf(u0x, u1x), fminf(u0y, u1y)), fminf(u0z, u1z));
             float f1 = fminf(fminf(fmaxf(u0x, u1x), fmaxf(u0y, u1y)), fmaxf(u0z, u1z));
             /* children with a sphere below are not culled by distance (phantom tangent hits) */
-            bool h0 = (f0 * 1.0000004f >= n0) && (f0 >= 0.0f) && ((n0 * 0.9999996f < h.best_t) || (c0 & SPHERE_BELOW_BIT));
-            bool h1 = (f1 * 1.0000004f >= n1) && (f1 >= 0.0f) && ((n1 * 0.9999996f < h.best_t) || (c1 & SPHERE_BELOW_BIT)) && (c1 != EMPTY_CHILD);
+            bool h0 = (f0 * 1.0000004f >= n0) && (f0 >= 0.0f) && ((n0 * kCullSlack < h.best_t) || (c0 & SPHERE_BELOW_BIT));
+            bool h1 = (f1 * 1.0000004f >= n1) && (f1 >= 0.0f) && ((n1 * kCullSlack < h.best_t) || (c1 & SPHERE_BELOW_BIT)) && (c1 != EMPTY_CHILD);
             if (h0 && h1) {
                 bool swap = n1 < n0;
                 uint32_t farc = swap ? c0 : c1;
@@ -704,7 +725,7 @@ ORT_D bool traverse(const SceneView &sv, V3 org, V3 dir, Trav &T, HitState &h, u
             ORT_UTIL(sv, 1, true);
             uint32_t kind = (cur >> 28) & 7u, count = ((cur >> 24) & 15u) + 1u, first = cur & 0x00ffffffu;
             for (uint32_t i = 0; i < count; ++i)
-                test_prim<COUNTERS, false>(sv, kind, first + i, org, dir, inv_d, h.best_t, h.hit_n, h.hit_prim, h.phantom_t, c.tris, c.analytic);
+                test_prim<COUNTERS, false>(sv, kind, first + i, org, dir, inv_d, h.best_t, h.hit_n, h.hit_prim, h.phantom_t, h.runner_t, c.tris, c.analytic);
             if (sp == 0) {
                 cur = kTraversalDone;
                 tracing = false;

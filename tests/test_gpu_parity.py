@@ -226,6 +226,24 @@ def test_every_ray_through_the_reference_order_walk(api, oracle, gpu_scene, monk
     assert_bits_equal(img, ref, "1/16 of the rays re-cast")
 
 
+@pytest.mark.parametrize("name,w,h,spp,seed,policy,chunk,x,y", [
+    ("c2_analytic", 480, 270, 32, 7066, "pixel", 0, 25, 100),
+    ("letters", 480, 270, 32, 7092, "chunk", 8, 8, 265),
+    ("c2_analytic", 480, 270, 32, 7186, "pixel", 0, None, None),
+    ("testscene", 256, 144, 16, 7425, "chunk", 8, None, None)])
+def test_hits_in_front_of_their_node_box(api, oracle, gpu_scene, name, w, h, spp, seed, policy, chunk, x, y):
+    """found by tools/stress_parity.py (7 single-pixel differences in 2.5e9 paths): the reference's cylinder
+    boxes are too small (r * (1 - |a_k|/|a|) instead of r * sqrt(1 - a_k^2)) and flat boxes round either way,
+    so a hit can lie in FRONT of its node's entry distance; the reference then sees it only if nothing
+    nearer than that entry was found earlier.  The chain check bounds the entry by the winner's distance or,
+    failing that, by the runner-up; else the ray is re-cast exactly."""
+    scene = gpu_scene(name)
+    rect = (0, 0, w, h) if x is None else (max(x - 3, 0), max(y - 3, 0), min(x + 4, w), min(y + 4, h))
+    img, _ = scene.render(w, h, spp, seed, policy, chunk=chunk, rect=rect)
+    ref, _ = oracle.OracleScene(scene.flatten(w, h)).render(w, h, spp, seed, policy, chunk=max(chunk, 1), rect=rect, threads=16)
+    assert_bits_equal(img[rect[1]:rect[3], rect[0]:rect[2]], ref[rect[1]:rect[3], rect[0]:rect[2]], name)
+
+
 # ---- synthetic scenes / edge cases -----------------------------------------------------------------
 def _random_scene(api, seed, n_sph=6, n_box=4, n_cyl=3, n_tri=40):
     rng = np.random.default_rng(seed)

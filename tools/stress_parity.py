@@ -1,0 +1,47 @@
+"""Developer script: one-off parity hunt on the GPU box -- many random scenes and larger renders of the
+fixture scenes, HIP path vs oracle, bit for bit.  Prints one line per case; exits 1 on any difference.
+usage: python3 tools/stress_parity.py [n_random=40] [budget_seconds=240]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from offline_raytracer_amd import api
+import oracle_lib
+import test_gpu_parity as T
+
+n_random = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+budget = float(sys.argv[2]) if len(sys.argv) > 2 else 240.0
+t_start = time.time()
+bad = 0
+
+
+def check(tag, scene, w, h, spp, seed, policy, chunk, csg):
+    global bad
+    img, st = scene.render(w, h, spp, seed, policy, chunk=chunk, counters=True)
+    ref, ost = oracle_lib.OracleScene(scene.flatten(w, h), with_reference_csg=csg).render(w, h, spp, seed, policy, chunk=max(chunk, 1), threads=16)
+    diff = int((img.view("<u4") != ref.view("<u4")).any(axis=2).sum())
+    bad += diff != 0
+    print("%-34s %4dx%-4d %3dspp %-5s c%-2d seed %-6d paths %9d fallback %6d : %s" %
+          (tag, w, h, spp, policy, chunk, seed, st["paths"], st["fallback_rays"], "ok" if diff == 0 else "DIFF in %d pixels" % diff), flush=True)
+
+
+rng = np.random.default_rng(2024)
+for i in range(n_random):
+    if time.time() - t_start > budget * 0.5:
+        break
+    seed = 500 + i
+    sc = T._random_scene(api, seed, n_sph=int(rng.integers(0, 12)), n_box=int(rng.integers(0, 8)), n_cyl=int(rng.integers(1, 6)),
+                         n_tri=int(rng.integers(0, 400))).commit().upload(0)
+    check("random scene %d" % seed, sc, 96, 72, 16, seed, "chunk", 4, False)
+    sc.close()
+cases = [("c2_analytic", 480, 270, 32), ("c4_dwarf_room", 480, 270, 32), ("letters", 480, 270, 32), ("glass_room", 480, 270, 32),
+         ("c3_bunny_room", 320, 180, 32), ("testscene", 256, 144, 16)]
+k = 0
+while time.time() - t_start < budget:
+    name, w, h, spp = cases[k % len(cases)]
+    sc = api.Scene.load_scn(os.path.join(ROOT, "data", name + ".scn")).commit().upload(0)
+    check(name, sc, w, h, spp, 7000 + k, "chunk" if k % 3 else "pixel", 8 if k % 3 else 0, True)
+    sc.close()
+    k += 1
+print("cases with differences:", bad)
+sys.exit(1 if bad else 0)
