@@ -35,13 +35,26 @@ for i in range(n_random):
     check("random scene %d" % seed, sc, 96, 72, 16, seed, "chunk", 4, False)
     sc.close()
 cases = [("c2_analytic", 480, 270, 32), ("c4_dwarf_room", 480, 270, 32), ("letters", 480, 270, 32), ("glass_room", 480, 270, 32),
-         ("c3_bunny_room", 320, 180, 32), ("testscene", 256, 144, 16)]
+         ("c3_bunny_room", 320, 180, 32), ("testscene", 256, 144, 16), ("c5", 240, 135, 8)]
+seed0 = int(os.environ.get("STRESS_SEED0", "7000"))
+scenes = {}
+for name, _, _, _ in cases:
+    if name == "c5":
+        import tempfile
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import make_heightfield
+        path, _, _ = make_heightfield.write_scene(224, tempfile.mkdtemp(prefix="c5_"))
+    else:
+        path = os.path.join(ROOT, "data", name + ".scn")
+    scenes[name] = api.Scene.load_scn(path).commit().upload(0)
 k = 0
 while time.time() - t_start < budget:
     name, w, h, spp = cases[k % len(cases)]
-    sc = api.Scene.load_scn(os.path.join(ROOT, "data", name + ".scn")).commit().upload(0)
-    check(name, sc, w, h, spp, 7000 + k, "chunk" if k % 3 else "pixel", 8 if k % 3 else 0, True)
-    sc.close()
+    sc = scenes[name]
+    if k % 11 == 10:  # the reference's own schedules: long serial jobs
+        check(name, sc, 96, 64, 2, seed0 + k, "tile32" if k % 2 else "whole", 0, True)
+    else:
+        check(name, sc, w, h, spp, seed0 + k, "chunk" if k % 3 else "pixel", 8 if k % 3 else 0, True)
     k += 1
 print("cases with differences:", bad)
 sys.exit(1 if bad else 0)
