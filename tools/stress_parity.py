@@ -49,10 +49,38 @@ for name, _, _, _ in cases:
     else:
         path = os.path.join(ROOT, "data", name + ".scn")
     scenes[name] = api.Scene.load_scn(path).commit().upload(0)
+def check_batch(name, sc, seed):
+    """the batch form of the single call: random disjoint rects (some empty, some one pixel), random nonzero
+    RNG states and sample counts, one lane per job; image and every final RNG state against the oracle"""
+    global bad
+    r = np.random.default_rng(seed)
+    w, h = 96, 64
+    cells = [(cx, cy) for cy in range(0, h, 16) for cx in range(0, w, 16)]
+    r.shuffle(cells)
+    jobs = np.zeros(len(cells), api.JOB_DTYPE)
+    for i, (cx, cy) in enumerate(cells):
+        x0 = cx + int(r.integers(0, 8)); y0 = cy + int(r.integers(0, 8))
+        x1 = x0 + int(r.integers(0, 9)); y1 = y0 + int(r.integers(0, 9))  # width / height 0 => empty rect
+        jobs[i] = (x0, y0, min(x1, w), min(y1, h), int(r.integers(1, 2 ** 32)), int(r.integers(1, 5)))
+    out = np.zeros((h, w, 3), "<f4")
+    finals, _ = sc.tiled_raytrace_batch(out, jobs)
+    ref = np.zeros((h, w, 3), "<f4")
+    osc = oracle_lib.OracleScene(sc.flatten(w, h))
+    states_ok = True
+    for i, j in enumerate(jobs):
+        _, st = osc.tiled_raytrace(ref, int(j["x0"]), int(j["y0"]), int(j["x1"]), int(j["y1"]), int(j["rng_state"]), int(j["spp"]))
+        states_ok &= (finals[i] == st)
+    diff = int((out.view("<u4") != ref.view("<u4")).any(axis=2).sum())
+    bad += (diff != 0) or (not states_ok)
+    print("%-34s batch of %d jobs seed %-6d : %s" % (name, len(jobs), seed, "ok" if diff == 0 and states_ok else "DIFF px %d states %s" % (diff, states_ok)), flush=True)
+
+
 k = 0
 while time.time() - t_start < budget:
     name, w, h, spp = cases[k % len(cases)]
     sc = scenes[name]
+    if k % 5 == 4 and name != "c5":
+        check_batch(name, sc, seed0 + k)
     if k % 11 == 10:  # the reference's own schedules: long serial jobs
         check(name, sc, 96, 64, 2, seed0 + k, "tile32" if k % 2 else "whole", 0, True)
     else:
