@@ -339,7 +339,8 @@ ORT_D bool chain_admits(const SceneView &sv, uint32_t prim, V3 org, V3 inv_d, fl
 /* exact fallback: raycast_bvh (ray.cpp:624-822) emulated literally on the reference-compatible
    octree -- breadth-first, children in slot order, records in push order, a child admitted when
    the origin is inside it or 1e-6 <= t_entry < best AT THAT MOMENT.  The reference never reuses
-   queue memory within a ray; the emulation keeps only the live entries in a ring in HBM.
+   queue memory within a ray; the emulation appends to one queue of the pool in HBM (a ray enqueues a node
+   at most once, so ref_node_count entries are enough).
    Returns false if the queue overflowed (the render call then fails). */
 template <bool COUNTERS>
 ORT_D bool ref_raycast_bfs(const SceneView &sv, V3 org, V3 dir, V3 inv_d, uint32_t *queue, float &best_t, V3 &hit_n,
@@ -860,7 +861,7 @@ ORT_D void combine_pixel(const RenderView &rv, unsigned long long idx) {
 
 #ifndef ORT_HOST_SIM
 #ifndef ORT_WAVES_PER_EU
-#define ORT_WAVES_PER_EU 4 /* VGPR budget: 4 waves/SIMD = 128 registers, 16 spilled (tuned on MI355X: profiles/r01_tuning.md) */
+#define ORT_WAVES_PER_EU 4 /* VGPR budget: 4 waves/SIMD = 128 registers, 7 (diffuse flavour) / 26 (general) spilled; tuned on MI355X: profiles/r01_tuning.md */
 #endif
 /* DIFFUSE: every surface material of the uploaded scene has Ks = Kt = 0, so the evaluation and pdf
    of the specular / transmission lobes are compiled out (sampling keeps all three lobes: a draw of
@@ -873,7 +874,7 @@ pt_persistent(SceneView sv, RenderView rv) {
 }
 
 /* wavefront kernels: fixed-size grids, grid-stride over the slots (so a lane id < grid size indexes
-   the fallback rings) */
+   nothing but the launch geometry) */
 template <bool COUNTERS>
 __global__ void __launch_bounds__(kBlock) wf_shade(SceneView sv, RenderView rv, WfView wf, int count_active) {
     Counters c;
@@ -1296,7 +1297,7 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
 
     if (!d_out && h_out) ORT_HIP(hipMemcpyAsync(h_out, out, image_bytes, hipMemcpyDeviceToHost, stream));
     if (final_states) ORT_HIP(hipMemcpyAsync(final_states, d->states, (size_t)job_count * 4u, hipMemcpyDeviceToHost, stream));
-    /* a fallback ring overflow must not go unnoticed: every synchronous form of the call checks it
+    /* a fallback queue overflow (cannot happen by construction; tripwire) must not go unnoticed: every synchronous form of the call checks it
        (the fire-and-forget device form, stats == NULL, cannot without a sync; bench.py asks for stats) */
     if (stats || !d_out || final_states) {
         ORT_HIP(hipStreamSynchronize(stream));
