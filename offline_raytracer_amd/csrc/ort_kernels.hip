@@ -873,8 +873,7 @@ pt_persistent(SceneView sv, RenderView rv) {
     pt_lane<COUNTERS, DIFFUSE>(sv, rv, lds_stack, (int)threadIdx.x, blockIdx.x * (uint32_t)kBlock + threadIdx.x);
 }
 
-/* wavefront kernels: fixed-size grids, grid-stride over the slots (so a lane id < grid size indexes
-   nothing but the launch geometry) */
+/* wavefront kernels: fixed-size grids, grid-stride over the slots */
 template <bool COUNTERS>
 __global__ void __launch_bounds__(kBlock) wf_shade(SceneView sv, RenderView rv, WfView wf, int count_active) {
     Counters c;
