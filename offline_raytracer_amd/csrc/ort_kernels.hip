@@ -79,6 +79,7 @@ struct RenderView {
     int descend_below; /* leave the descend loop (to process the leaves already reached, and perhaps refill) when
                           fewer lanes than this are still walking interior nodes */
     uint32_t shard_index, shard_count, blocks_w, my_blocks;
+    uint32_t block_x0, block_y0; /* unsharded renders enumerate only the 8x8 blocks that touch the rect */
     float *out;      /* W*H*3 */
     float *partial;  /* nchunks * W*H*3 (CHUNK) */
     unsigned long long *next_job;
@@ -565,8 +566,8 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderView &rv, PathState &P, 
                     uint32_t rem = (uint32_t)(j % per_chunk);
                     uint32_t blk = rv.shard_index + (rem >> 6) * rv.shard_count;
                     uint32_t pin = rem & 63u;
-                    int x = (int)((blk % rv.blocks_w) * 8u + (pin & 7u));
-                    int y = (int)((blk / rv.blocks_w) * 8u + (pin >> 3));
+                    int x = (int)((rv.block_x0 + blk % rv.blocks_w) * 8u + (pin & 7u));
+                    int y = (int)((rv.block_y0 + blk / rv.blocks_w) * 8u + (pin >> 3));
                     if (x < rv.x0 || x >= rv.x1 || y < rv.y0 || y >= rv.y1) continue;
                     uint32_t pix = (uint32_t)(y * rv.W + x);
                     P.jxx = (uint32_t)x | ((uint32_t)(x + 1) << 16);
@@ -844,8 +845,8 @@ ORT_D void wf_trace_slot(const SceneView &sv, const WfView &wf, uint32_t i, uint
 ORT_D void combine_pixel(const RenderView &rv, unsigned long long idx) {
     uint32_t blk = rv.shard_index + (uint32_t)(idx >> 6) * rv.shard_count;
     uint32_t pin = (uint32_t)(idx & 63ull);
-    int x = (int)((blk % rv.blocks_w) * 8u + (pin & 7u));
-    int y = (int)((blk / rv.blocks_w) * 8u + (pin >> 3));
+    int x = (int)((rv.block_x0 + blk % rv.blocks_w) * 8u + (pin & 7u));
+    int y = (int)((rv.block_y0 + blk / rv.blocks_w) * 8u + (pin >> 3));
     if (x < rv.x0 || x >= rv.x1 || y < rv.y0 || y >= rv.y1) return;
     size_t pix = (size_t)y * (size_t)rv.W + (size_t)x;
     size_t plane = (size_t)rv.W * (size_t)rv.H * 3u;
@@ -1239,6 +1240,15 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
     rv.shard_index = p->shard_count > 1 ? p->shard_index : 0;
     rv.blocks_w = (uint32_t)((p->width + 7) / 8);
     uint32_t blocks_total = rv.blocks_w * (uint32_t)((p->height + 7) / 8);
+    rv.block_x0 = rv.block_y0 = 0;
+    if (rv.shard_count == 1 && !jobs && p->x1 > p->x0 && p->y1 > p->y0) {
+        /* one GPU: only the blocks under the rect (sharded renders keep the global numbering, which is
+           what block_id % world == rank and dist.py's packing refer to) */
+        rv.block_x0 = (uint32_t)(p->x0 / 8);
+        rv.block_y0 = (uint32_t)(p->y0 / 8);
+        rv.blocks_w = (uint32_t)((p->x1 + 7) / 8) - rv.block_x0;
+        blocks_total = rv.blocks_w * ((uint32_t)((p->y1 + 7) / 8) - rv.block_y0);
+    }
     rv.my_blocks = (blocks_total > rv.shard_index) ? (blocks_total - rv.shard_index + rv.shard_count - 1) / rv.shard_count : 0;
 
     if (jobs) {

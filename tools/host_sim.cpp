@@ -71,6 +71,7 @@ int main(int argc, char **argv) {
     rv.out = out.data(); rv.next_job = ctrl; rv.counters = ctrl + 1;
     sv.fallback_counters = ctrl + 6;
     rv.shard_count = argc > 11 ? (uint32_t)atoi(argv[11]) : 1; rv.shard_index = argc > 11 ? (uint32_t)atoi(argv[10]) : 0;
+    rv.block_x0 = rv.block_y0 = 0;
     rv.blocks_w = (uint32_t)((W + 7) / 8);
     uint32_t blocks_total = rv.blocks_w * (uint32_t)((H + 7) / 8);
     rv.my_blocks = (blocks_total - rv.shard_index + rv.shard_count - 1) / rv.shard_count;
