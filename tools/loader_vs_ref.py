@@ -1,0 +1,77 @@
+"""Developer script (dev container only: needs oracle/_ref/ref_det): random .scn texts in the reference's grammar --
+random literals in several spellings (plain, many digits, leading '-', exponents on float mantissas), random
+mesh placements of the reference's own mesh files -- through the reference's parser + placement (scene-dump)
+and through the product's loader; the digests (every array's bytes) must be equal.
+usage: python3 tools/loader_vs_ref.py N_SCENES"""
+import os, subprocess, sys, tempfile, shutil
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import ref_io
+from offline_raytracer_amd import api
+
+REF = os.path.join(ROOT, "oracle", "_ref", "ref_det")
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+work = tempfile.mkdtemp(prefix="scn_")          # no '.' in the directory name (reference's get_extension)
+for f in ("dwarf.obj", "letterX.ply", "letterY.ply", "bunny.ply"):
+    shutil.copy(os.path.join(ROOT, "data", f), work)
+rng = np.random.default_rng(12)
+
+
+def f32lit(lo, hi):
+    v = rng.uniform(lo, hi)
+    style = rng.integers(0, 6)
+    if style == 0: return "%.6f" % v
+    if style == 1: return "%.3f" % v
+    if style == 2: return "%.12f" % v
+    if style == 3: return "%.1f" % v
+    if style == 4: return ("%.4fe%d" % (v / 10.0, 1)) if abs(v) > 1e-3 else "%.6f" % v   # float mantissa with exponent
+    return "%.9f" % v
+
+
+def scene_text(i):
+    L = ["screen %d %d" % (rng.integers(16, 2000), rng.integers(16, 2000)),
+         "camera %s %s %s b %s q %s %s %s %s" % (f32lit(-6, 6), f32lit(-6, 6), f32lit(0.5, 6), f32lit(0.05, 0.9), f32lit(-1, 1), f32lit(-1, 1), f32lit(-1, 1), f32lit(-1, 1)),
+         "ambient %s %s %s" % (f32lit(0, 1), f32lit(0, 1), f32lit(0, 1))]
+    for _ in range(int(rng.integers(3, 25))):
+        kind = rng.integers(0, 7)
+        if kind <= 1 or len(L) == 3:
+            if rng.integers(0, 4) == 0:
+                L.append("light %d %d %d" % (rng.integers(0, 9), rng.integers(0, 9), rng.integers(0, 9)))
+            else:
+                tail = " %s %s %s %s" % (f32lit(0, 1), f32lit(0, 1), f32lit(0, 1), f32lit(1, 2)) if rng.integers(0, 2) else ""
+                L.append("brdf %s %s %s %s %s %s %d%s" % (f32lit(0, 1), f32lit(0, 1), f32lit(0, 1), f32lit(0, 1), f32lit(0, 1), f32lit(0, 1), rng.integers(1, 300), tail))
+        elif kind == 2:
+            L.append("sphere %s %s %s %s" % (f32lit(-3, 3), f32lit(-3, 3), f32lit(0, 3), f32lit(0.01, 1)))
+        elif kind == 3:
+            L.append("box %s %s %s %s %s %s" % (f32lit(-3, 3), f32lit(-3, 3), f32lit(-1, 3), f32lit(0.01, 4), f32lit(0.01, 4), f32lit(0.01, 4)))
+        elif kind == 4:
+            L.append("cylinder %s %s %s %s %s %s %s" % (f32lit(-3, 3), f32lit(-3, 3), f32lit(0, 3), f32lit(-3, 3), f32lit(-3, 3), f32lit(-3, 3), f32lit(0.01, 0.5)))
+        else:
+            mesh = ["dwarf.obj", "letterX.ply", "letterY.ply"][int(rng.integers(0, 3))] if rng.integers(0, 8) else "bunny.ply"
+            rot = ("z %d " % rng.integers(-180, 180)) if rng.integers(0, 2) else (("z %s " % f32lit(-180, 180)) if rng.integers(0, 2) else "")
+            quat = " ".join(f32lit(-1, 1) if rng.integers(0, 3) else str(int(rng.integers(0, 2))) for _ in range(4))
+            L.append("mesh %s  %s %s %s %s  %sq %s" % (mesh, f32lit(-2, 2), f32lit(-2, 2), f32lit(0, 2), f32lit(0.01, 5), rot, quat))
+    return "\n".join(L) + "\n"
+
+
+bad = 0
+for i in range(n):
+    text = scene_text(i)
+    scn = os.path.join(work, "r%d.scn" % i)
+    open(scn, "w").write(text)
+    dump = os.path.join(work, "d.bin")
+    r = subprocess.run([REF, "scene-dump", scn, work + "/", "64", "48", dump], capture_output=True, text=True)
+    if r.returncode != 0:
+        print("scene %d: reference rejected it (rc %d), skipped" % (i, r.returncode)); continue
+    want = ref_io.scene_digest(ref_io.read_scene_dump(dump))
+    flat = api.Scene.load_scn(scn).flatten(64, 48)
+    flat.root_aabb = None
+    got = ref_io.scene_digest(flat)
+    keys = ("counts", "camera_bits", "ambient_bits", "materials_sha256", "spheres_sha256", "boxes_sha256", "cylinders_sha256", "lights", "meshes", "sha256")
+    diff = [k for k in keys if got[k] != want[k]]
+    if diff:
+        bad += 1
+        print("scene %d DIFFERS in %s (kept as %s)" % (i, diff, scn))
+print("%d random scenes, %d with differences" % (n, bad))
+sys.exit(1 if bad else 0)
