@@ -65,11 +65,17 @@ for i in range(n):
     if r.returncode != 0:
         print("scene %d: reference rejected it (rc %d), skipped" % (i, r.returncode)); continue
     want = ref_io.scene_digest(ref_io.read_scene_dump(dump))
-    flat = api.Scene.load_scn(scn).flatten(64, 48)
+    import json
+    octree = json.loads(r.stdout.strip().splitlines()[-1])
+    sc = api.Scene.load_scn(scn)
+    flat = sc.flatten(64, 48)
     flat.root_aabb = None
     got = ref_io.scene_digest(flat)
     keys = ("counts", "camera_bits", "ambient_bits", "materials_sha256", "spheres_sha256", "boxes_sha256", "cylinders_sha256", "lights", "meshes", "sha256")
     diff = [k for k in keys if got[k] != want[k]]
+    ti = sc.commit().tree_info()  # the reference-compatible octree: node and non-empty-leaf counts
+    if ti["ref_node_count"] != octree["octree_nodes"] or ti["ref_nonempty_leaves"] != octree["octree_leaves"]:
+        diff.append("octree %s vs %s" % ((ti["ref_node_count"], ti["ref_nonempty_leaves"]), (octree["octree_nodes"], octree["octree_leaves"])))
     if diff:
         bad += 1
         print("scene %d DIFFERS in %s (kept as %s)" % (i, diff, scn))
