@@ -29,7 +29,7 @@ REF_GLIBC = os.path.join(ROOT, "oracle", "_ref", "ref_glibc")
 DATA = os.path.join(ROOT, "data") + "/"
 TMP = tempfile.mkdtemp(prefix="golden_")
 
-SCENES = ["testscene", "c2_analytic", "c3_bunny_room", "c4_dwarf_room", "letters", "glass_room"]
+SCENES = ["testscene", "c2_analytic", "c3_bunny_room", "c4_dwarf_room", "letters", "glass_room", "rand_a", "rand_b"]
 # (policy, W, H, spp, chunk, seed)
 RENDERS = [("tile32", 64, 64, 2, 1, 12345), ("whole", 24, 16, 2, 1, 999), ("pixel", 40, 30, 3, 1, 7),
            ("chunk", 40, 30, 4, 2, 7), ("sample", 33, 17, 3, 1, 31337)]
@@ -229,6 +229,37 @@ def main():
         "sphere -1.000000 0.800000 0.700000 0.3\n"
         "cylinder 1.200000 -1.200000 0.400000 -0.000000 2.400000 0.000000 0.05\n"
         "light 3 3 2\nsphere 0.000000 0.000000 2.800000 0.9\n")
+
+    # two machine-written scenes: the closed room, then random shapes / materials / rotated meshes, numbers in
+    # several spellings (plain, many digits, exponent on a float mantissa)
+    for tag, sd in (("rand_a", 101), ("rand_b", 202)):
+        r = np.random.default_rng(sd)
+
+        def lit(lo, hi):
+            v = r.uniform(lo, hi)
+            k = int(r.integers(0, 4))
+            return ("%.6f" % v) if k == 0 else ("%.3f" % v) if k == 1 else ("%.11f" % v) if k == 2 else ("%.5fe1" % (v / 10.0))
+        L = [room.rstrip("\n")]
+        for _ in range(14):
+            kind = int(r.integers(0, 6))
+            if kind == 0:
+                L.append("brdf %s %s %s 0.000000 0.000000 0.000000 %d" % (lit(0.1, 0.9), lit(0.1, 0.9), lit(0.1, 0.9), r.integers(1, 200)))
+            elif kind == 1:
+                L.append("brdf %s %s %s %s %s %s %d %s %s %s %s" % (lit(0, 0.5), lit(0, 0.5), lit(0, 0.5), lit(0, 1), lit(0, 1), lit(0, 1), r.integers(1, 200),
+                                                                 lit(0, 1), lit(0, 1), lit(0, 1), lit(1.05, 1.6)))
+            elif kind == 2:
+                L.append("sphere %s %s %s %s" % (lit(-2.5, 2.5), lit(-2.5, 2.5), lit(0.3, 2.5), lit(0.05, 0.6)))
+            elif kind == 3:
+                L.append("box %s %s %s %s %s %s" % (lit(-2.5, 2), lit(-2.5, 2), lit(0, 2), lit(0.1, 1), lit(0.1, 1), lit(0.1, 1)))
+            elif kind == 4:
+                L.append("cylinder %s %s %s %s %s %s %s" % (lit(-2.5, 2.5), lit(-2.5, 2.5), lit(0, 2), lit(-1.5, 1.5), lit(-1.5, 1.5), lit(-1.5, 1.5), lit(0.03, 0.3)))
+            else:
+                mesh, scale = [("dwarf.obj", (0.008, 0.02)), ("letterX.ply", (0.2, 0.5)), ("letterY.ply", (0.2, 0.5))][int(r.integers(0, 3))]
+                rot = ("z %d " % r.integers(-180, 180)) if r.integers(0, 2) else "z %s " % lit(-180, 180)
+                L.append("mesh %s  %s %s %s %s  %sq %s %s %s %s" % (mesh, lit(-1.5, 1.5), lit(-1.5, 1.5), lit(0.5, 2), lit(*scale), rot,
+                                                                   lit(-1, 1), lit(-1, 1), lit(-1, 1), lit(-1, 1)))
+        L.append("light 3 3 2\nsphere 0.000000 0.000000 2.800000 0.9")
+        open(DATA + tag + ".scn", "w").write("\n".join(L) + "\n")
 
     # RNG streams (random.h)
     for seed in (12345, 1, 4294967295, 2463534242):

@@ -12,7 +12,7 @@ from conftest import GOLDEN, assert_bits_equal
 
 pytestmark = pytest.mark.gpu
 
-SCENES = ["testscene", "c2_analytic", "c3_bunny_room", "c4_dwarf_room", "letters", "glass_room"]
+SCENES = ["testscene", "c2_analytic", "c3_bunny_room", "c4_dwarf_room", "letters", "glass_room", "rand_a", "rand_b"]
 # + the 99 458-triangle decimation of BASELINE.json's synthetic-mesh config (generated, see conftest.load_scene)
 SCENES_C5 = SCENES + ["c5_heightfield_224"]
 
