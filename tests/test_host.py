@@ -260,3 +260,27 @@ def test_mesh_paths_with_dotted_directories(api, tmp_path):
     (d / "bad.scn").write_text("brdf 0.5 0.5 0.5 0.0 0.0 0.0 10\nmesh dwarf.xyz 0.0 0.0 0.0 1.0\n")
     with pytest.raises(api.OrtError):
         api.Scene.load_scn(str(d / "bad.scn"))
+
+
+def test_rgbe_consistent_with_reference_output_file(api):
+    """tests/golden/showcase1_crop.npz holds the header and a 32x64-pixel crop of showcase/1.hdr, an image
+    the reference itself wrote (v3_to_rgbe lives in the macOS-only translation unit and cannot be compiled
+    here, so this is the only reference OUTPUT the writer can be held against).  Header text and file size
+    follow the same rule as ours; every pixel is 0 or has its largest mantissa byte in [128, 255] (frexp
+    normalisation); and decoding a pixel (byte * 2^(e-128) / 255) and encoding it again with the product's
+    encoder reproduces the reference's four bytes (except where the top byte is 255: m = 1.0 renormalises)."""
+    z = np.load(os.path.join(GOLDEN, "showcase1_crop.npz"))
+    header = bytes(z["header"])
+    assert header == b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n+Y 720 +X 1280\n"
+    assert int(z["file_size"]) == len(header) + 1280 * 720 * 4
+    px = z["rgbe"].astype(np.int64).reshape(-1, 4)
+    top = px[:, :3].max(axis=1)
+    nonzero = px[:, 3] > 0
+    assert ((top[nonzero] >= 128) & (top[nonzero] <= 255)).all()
+    checked = 0
+    for r, g, b, e in px[nonzero & (top < 255)]:
+        s = float(np.ldexp(1.0, int(e) - 128)) / 255.0
+        want = int(r) | int(g) << 8 | int(b) << 16 | int(e) << 24
+        assert api.rgbe(np.float32(r * s), np.float32(g * s), np.float32(b * s)) == want
+        checked += 1
+    assert checked > 1500
