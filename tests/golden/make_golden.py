@@ -201,7 +201,20 @@ def golden_c5(manifest):
     np.savez_compressed(os.path.join(HERE, "renders_%s.npz" % name), **arrays)
 
 
+def golden_showcase():
+    """a crop of an image the reference itself wrote (showcase/1.hdr): header, file size, 32x64 RGBE pixels"""
+    raw = open("/root/reference/showcase/1.hdr", "rb").read()
+    hdr = b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n+Y 720 +X 1280\n"
+    assert raw.startswith(hdr)
+    px = np.frombuffer(raw[len(hdr):], dtype=np.uint8).reshape(720, 1280, 4)
+    np.savez_compressed(os.path.join(HERE, "showcase1_crop.npz"), header=np.frombuffer(hdr, dtype=np.uint8), file_size=np.int64(len(raw)),
+                        rows=np.array([300, 332]), cols=np.array([560, 624]), rgbe=np.ascontiguousarray(px[300:332, 560:624]))
+
+
 def main():
+    if "--only-showcase" in sys.argv:
+        golden_showcase()
+        return
     if "--only-c5" in sys.argv:  # add / refresh the C5 fixtures without touching the others
         manifest = json.load(open(os.path.join(HERE, "manifest.json")))
         golden_c5(manifest)
@@ -317,6 +330,7 @@ def main():
         np.savez_compressed(os.path.join(HERE, "raycast_%s.npz" % name), rays=rays, t=hits["t"], n=hits["n"], mat=hits["mat"])
 
     golden_c5(manifest)
+    golden_showcase()
 
     # cross-check values recorded by the survey, re-measured here on ref_glibc
     js = run(REF_GLIBC, "render", DATA + "testscene.scn", DATA, 64, 64, 4, 12345, "whole", os.path.join(TMP, "x.f32"))
