@@ -1220,8 +1220,12 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
     rv.seed = p->seed; rv.spp = p->spp; rv.chunk = p->chunk; rv.rr = p->rr;
     rv.out = out;
     {
-        const char *e = getenv("ORT_REFILL_BELOW"); /* tuning knob; results do not depend on it */
-        rv.refill_below = e ? atoi(e) : 12; /* tuned on MI355X: profiles/r01_tuning.md */
+        /* tuning knobs; results do not depend on them.  Defaults tuned on MI355X (profiles/r01_tuning.md)
+           separately for trees that stay in L2 and trees that do not */
+        const size_t fast_tree_bytes = scene->tree.nodes.size() * sizeof(DevNode) + scene->tree.tris.size() * sizeof(DevTri);
+        const bool cache_resident = fast_tree_bytes <= (size_t)(16u << 20);
+        const char *e = getenv("ORT_REFILL_BELOW");
+        rv.refill_below = e ? atoi(e) : (cache_resident ? 12 : 32);
         if (rv.refill_below < 1) rv.refill_below = 1;
         if (rv.refill_below > 64) rv.refill_below = 64;
         e = getenv("ORT_DESCEND_BELOW");
@@ -1229,8 +1233,7 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
            scene (86 MB, 60 % L2 hits, latency-bound) it halves the throughput of long launches -- L2 read
            latency 270 -> 690 cycles at equal request counts, not understood (profiles/r01_tuning.md) --
            so trees that cannot stay in the 8 x 4 MB of L2 keep the plain while-while loop */
-        const size_t fast_tree_bytes = scene->tree.nodes.size() * sizeof(DevNode) + scene->tree.tris.size() * sizeof(DevTri);
-        rv.descend_below = e ? atoi(e) : (fast_tree_bytes <= (size_t)(16u << 20) ? 8 : 0);
+        rv.descend_below = e ? atoi(e) : (cache_resident ? 8 : 0);
         if (rv.descend_below < 0) rv.descend_below = 0;
         if (rv.descend_below > 64) rv.descend_below = 64;
     }
