@@ -6,6 +6,11 @@
  * Every function names the reference lines it follows (paths relative to
  * /root/reference/code).  Build with -ffp-contract=off: the reference's own output
  * changes under FMA contraction.  libm -> det_math.h.
+ *
+ * PINNED: bit-identical to the reference compiled from its own sources (oracle/_ref/ref_det, recipe in
+ * oracle/Makefile) -- images, the reference's shapes_tested counter and final RNG state in all seeding
+ * policies, closest-hit tables, per-function tables: tests/golden/ (tests/test_oracle_golden.py), and
+ * 1 343 further renders on fresh seeds (tools/oracle_vs_ref.py, profiles/r01_stress_parity.md).
  */
 #include "ort_oracle.h"
 #include "det_math.h"
