@@ -454,11 +454,20 @@ ORT_D void resolve_hit(const SceneView &sv, V3 org, V3 dir, V3 inv_d, uint32_t l
     }
 }
 
+/* ray.cpp:1215-1221: the point on the focal plane through the centre of pixel pxy = x | y << 16 */
+ORT_D V3 focal_point(const RenderView &rv, uint32_t pxy, V3 cam_p, V3 cam_x, V3 cam_y, V3 cam_z, float focal_length) {
+    float fx = (2.0f * (int)(pxy & 0xffffu) / (float)rv.W) - 1.0f; /* i32 -> f32, as the reference's x, y */
+    float fy = (2.0f * (int)(pxy >> 16) / (float)rv.H) - 1.0f;
+    V3 to_pixel = normalize(sub(add(scale(fx, cam_x), scale(fy, cam_y)), cam_z));
+    return add(cam_p, scale(focal_length, to_pixel));
+}
+
 /* Advance the lane's path state machine until it has produced the next ray (returns true; the ray
    is P.org / P.dir) or has run out of work (returns false).  On entry with P.ps == PS_HIT, h holds
    the resolved closest hit of the ray produced by the previous call. */
 template <bool COUNTERS, bool DIFFUSE = false>
-ORT_D bool produce_ray(const SceneView &sv, const RenderView &rv, PathState &P, const HitState &h, Counters &c) {
+ORT_D bool produce_ray(const SceneView &sv, const RenderView &rv, PathState &P, const HitState &h, Counters &c,
+                       float *focal_cache = nullptr, int focal_stride = 0) {
     const V3 cam_p = mk(sv.cam[0], sv.cam[1], sv.cam[2]);
     const V3 cam_x = mk(sv.cam[3], sv.cam[4], sv.cam[5]);
     const V3 cam_y = mk(sv.cam[6], sv.cam[7], sv.cam[8]);
@@ -589,14 +598,16 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderView &rv, PathState &P, 
                 P.color = mk(0, 0, 0); /* ray.cpp:1211 */
                 P.sample = 0;
                 P.ps = PS_SAMPLE;
+                if (focal_cache) { /* the pixel's focal point, once per pixel (persistent kernel: three floats of LDS per lane) */
+                    V3 f = focal_point(rv, P.pxy, cam_p, cam_x, cam_y, cam_z, focal_length);
+                    focal_cache[0] = f.x; focal_cache[focal_stride] = f.y; focal_cache[2 * focal_stride] = f.z;
+                }
             }
             if (P.sample == P.spp) continue; /* spp == 0: the reference's sample loop runs zero times */
-            /* ray.cpp:1215-1221: point on the focal plane through the pixel centre (recomputed per
-               sample instead of held in registers: same expressions, same bits) */
-            float fx = (2.0f * (int)(P.pxy & 0xffffu) / (float)rv.W) - 1.0f; /* i32 -> f32, as the reference's x, y */
-            float fy = (2.0f * (int)(P.pxy >> 16) / (float)rv.H) - 1.0f;
-            V3 to_pixel = normalize(sub(add(scale(fx, cam_x), scale(fy, cam_y)), cam_z));
-            focal = add(cam_p, scale(focal_length, to_pixel));
+            /* ray.cpp:1215-1221: point on the focal plane through the pixel centre: a function of the pixel alone,
+               read back from the per-lane cache or (wavefront mode) recomputed -- same expressions, same bits */
+            focal = focal_cache ? mk(focal_cache[0], focal_cache[focal_stride], focal_cache[2 * focal_stride])
+                                : focal_point(rv, P.pxy, cam_p, cam_x, cam_y, cam_z, focal_length);
             angle = rng_between(P.rng, 0.0f, 2 * kPi); /* ray.cpp:1232 */
         }
         /* lanes that bounce and lanes that start a new camera sample both need cos/sin of one angle
@@ -759,7 +770,7 @@ ORT_D void flush_counters(const RenderView &rv, const Counters &c, bool all) {
 
 /* persistent mode: one lane runs jobs until the job space is empty */
 template <bool COUNTERS, bool DIFFUSE = false>
-ORT_D void pt_lane(const SceneView &sv, const RenderView &rv, uint32_t *lds_stack, const int tid, const uint32_t lane_id) {
+ORT_D void pt_lane(const SceneView &sv, const RenderView &rv, uint32_t *lds_stack, float *lds_focal, const int tid, const uint32_t lane_id) {
     uint32_t spill[kSpillStack];
     PathState P;
     HitState h;
@@ -771,7 +782,7 @@ ORT_D void pt_lane(const SceneView &sv, const RenderView &rv, uint32_t *lds_stac
             ORT_UTIL(sv, 3, true);
             ORT_UTIL(sv, 4, P.ps == PS_HIT);
             if (P.ps == PS_HIT) resolve_hit<COUNTERS>(sv, P.org, P.dir, T.inv_d, lane_id, h, c);
-            tracing = produce_ray<COUNTERS, DIFFUSE>(sv, rv, P, h, c);
+            tracing = produce_ray<COUNTERS, DIFFUSE>(sv, rv, P, h, c, lds_focal + tid, kBlock);
             if (tracing) {
                 begin_ray(P, T, h);
                 if (COUNTERS) c.rays++;
@@ -871,7 +882,8 @@ template <bool COUNTERS, bool DIFFUSE>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(ORT_WAVES_PER_EU, ORT_WAVES_PER_EU)))
 pt_persistent(SceneView sv, RenderView rv) {
     __shared__ uint32_t lds_stack[kLdsStack * kBlock];
-    pt_lane<COUNTERS, DIFFUSE>(sv, rv, lds_stack, (int)threadIdx.x, blockIdx.x * (uint32_t)kBlock + threadIdx.x);
+    __shared__ float lds_focal[3 * kBlock]; /* focal[component][lane] */
+    pt_lane<COUNTERS, DIFFUSE>(sv, rv, lds_stack, lds_focal, (int)threadIdx.x, blockIdx.x * (uint32_t)kBlock + threadIdx.x);
 }
 
 /* wavefront kernels: fixed-size grids, grid-stride over the slots */

@@ -100,6 +100,7 @@ int main(int argc, char **argv) {
     if (getenv("SIM_DUMP_RNG")) { g_pixel_rng = pix_rng.data(); g_W = W; }
     std::vector<uint32_t> lds(kLdsStack * kBlock);
     auto t0 = std::chrono::steady_clock::now();
+    std::vector<float> lds_focal(3 * kBlock);
     std::vector<uint32_t> bfsq(scene->ref.nodes.size() + 8), bfs_lock(1, 0u);
     sv.bfs_pool = bfsq.data();
     sv.bfs_locks = bfs_lock.data();
@@ -126,8 +127,8 @@ int main(int argc, char **argv) {
         }
         flush_counters(rv, c, true);
     } else
-    if (getenv("SIM_DIFFUSE")) pt_lane<true, true>(sv, rv, lds.data(), 0, 0); /* caller vouches for Ks = Kt = 0 */
-    else pt_lane<true>(sv, rv, lds.data(), 0, 0);
+    if (getenv("SIM_DIFFUSE")) pt_lane<true, true>(sv, rv, lds.data(), lds_focal.data(), 0, 0); /* caller vouches for Ks = Kt = 0 */
+    else pt_lane<true>(sv, rv, lds.data(), lds_focal.data(), 0, 0);
     if (rv.mode == JOBS_CHUNK)
         for (unsigned long long i = 0; i < (unsigned long long)rv.my_blocks * 64; ++i) combine_pixel(rv, i);
     double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
