@@ -246,6 +246,9 @@ ORT_D BrdfDraw sample_brdf_draw(uint32_t &rng, float rough, const Mat &mt) {
     return d;
 }
 /* finish: the direction from the lobe sample */
+/* NORMALIZED = false leaves ray.cpp:1158's final normalisation to the caller (the kernel shares it with the
+   camera branch's) */
+template <bool NORMALIZED = true>
 ORT_D V3 sample_brdf_finish(V3 N, V3 wo, const Mat &mt, BrdfDraw d, float cos_phi, float sin_phi, bool &is_trans) {
     float pd_c = mt.pd_c, ps_c = mt.ps_c; /* per material, ray.cpp:1105-1113 */
     V3 wi;
@@ -269,7 +272,7 @@ ORT_D V3 sample_brdf_finish(V3 N, V3 wo, const Mat &mt, BrdfDraw d, float cos_ph
             is_trans = true;
         }
     }
-    return normalize(wi); /* ray.cpp:1158 */
+    return NORMALIZED ? normalize(wi) : wi; /* ray.cpp:1158 */
 }
 ORT_D V3 sample_brdf(uint32_t &rng, V3 N, V3 wo, float rough, const Mat &mt, bool &is_trans) {
     BrdfDraw d = sample_brdf_draw(rng, rough, mt);

@@ -615,15 +615,22 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderView &rv, PathState &P, 
            converged, instead of once in each branch (same operand, same bits) */
         ORT_UTIL(sv, 7, true);
         float cs = ort_cosf(angle), sn = ort_sinf(angle);
+        /* both branches end by normalising a direction (ray.cpp:1158 / :1240): one converged evaluation */
+        V3 raw, ap = mk(0, 0, 0);
+        bool is_trans = false;
         if (bounce) {
-            bool is_trans;
-            V3 wi = sample_brdf_finish(n, P.wo, m, draw, cs, sn, is_trans);
-            if (is_trans) P.org = add(P.org, scale(2.0f * kEps, P.dir)); /* ray.cpp:1345-1348: dir is still the arriving direction */
-            P.dir = wi;
+            raw = sample_brdf_finish<false>(n, P.wo, m, draw, cs, sn, is_trans);
         } else {
             /* ray.cpp:1233-1246 */
-            V3 ap = sub(add(add(cam_p, scale(aperture * cs, cam_x)), scale(aperture * sn, cam_y)), scale(0.1f, cam_z));
-            P.dir = normalize(sub(focal, ap));
+            ap = sub(add(add(cam_p, scale(aperture * cs, cam_x)), scale(aperture * sn, cam_y)), scale(0.1f, cam_z));
+            raw = sub(focal, ap);
+        }
+        const V3 unit = normalize(raw);
+        if (bounce) {
+            if (is_trans) P.org = add(P.org, scale(2.0f * kEps, P.dir)); /* ray.cpp:1345-1348: dir is still the arriving direction */
+            P.dir = unit;
+        } else {
+            P.dir = unit;
             P.wo = neg(normalize(P.dir)); /* normalised again (sic) */
             P.org = ap;
             P.weight = mk(1, 1, 1);
