@@ -249,11 +249,11 @@ ORT_D BrdfDraw sample_brdf_draw(uint32_t &rng, float rough, const Mat &mt) {
 /* NORMALIZED = false leaves ray.cpp:1158's final normalisation to the caller (the kernel shares it with the
    camera branch's) */
 template <bool NORMALIZED = true>
-ORT_D V3 sample_brdf_finish(V3 N, V3 wo, const Mat &mt, BrdfDraw d, float cos_phi, float sin_phi, bool &is_trans) {
+ORT_D V3 sample_brdf_finish(V3 N, V3 Nn, V3 wo, const Mat &mt, BrdfDraw d, float cos_phi, float sin_phi, bool &is_trans) {
     float pd_c = mt.pd_c, ps_c = mt.ps_c; /* per material, ray.cpp:1105-1113 */
     V3 wi;
     is_trans = false;
-    V3 m = sample_lobe_n(normalize(N), d.c, cos_phi, sin_phi); /* ray.cpp:1069 re-normalises N */
+    V3 m = sample_lobe_n(Nn, d.c, cos_phi, sin_phi); /* Nn = normalize(N): ray.cpp:1069 re-normalises N */
     if (d.choice < pd_c) {
         wi = m;
     } else {
@@ -276,7 +276,7 @@ ORT_D V3 sample_brdf_finish(V3 N, V3 wo, const Mat &mt, BrdfDraw d, float cos_ph
 }
 ORT_D V3 sample_brdf(uint32_t &rng, V3 N, V3 wo, float rough, const Mat &mt, bool &is_trans) {
     BrdfDraw d = sample_brdf_draw(rng, rough, mt);
-    return sample_brdf_finish(N, wo, mt, d, ort_cosf(d.phi), ort_sinf(d.phi), is_trans);
+    return sample_brdf_finish(N, normalize(N), wo, mt, d, ort_cosf(d.phi), ort_sinf(d.phi), is_trans);
 }
 
 /* ---- intersectors ----------------------------------------------------------------------- */

@@ -615,27 +615,52 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderView &rv, PathState &P, 
            converged, instead of once in each branch (same operand, same bits) */
         ORT_UTIL(sv, 7, true);
         float cs = ort_cosf(angle), sn = ort_sinf(angle);
-        /* both branches end by normalising a direction (ray.cpp:1158 / :1240): one converged evaluation */
-        V3 raw, ap = mk(0, 0, 0);
-        bool is_trans = false;
-        if (bounce) {
-            raw = sample_brdf_finish<false>(n, P.wo, m, draw, cs, sn, is_trans);
+        if (DIFFUSE) { /* the leaner flavour has the registers for the wider merge; the all-lobes one spills on it */
+            /* Bounce lanes normalise twice here (the surface normal again, ray.cpp:1069, and the sampled direction,
+               :1158) and so do camera lanes (the ray direction, :1240, and -- sic -- the direction again for wo,
+               :1241): two converged evaluations instead of four divergent ones */
+            V3 ap = mk(0, 0, 0);
+            if (!bounce) /* ray.cpp:1233-1239 */
+                ap = sub(add(add(cam_p, scale(aperture * cs, cam_x)), scale(aperture * sn, cam_y)), scale(0.1f, cam_z));
+            const V3 unit1 = normalize(bounce ? n : sub(focal, ap));
+            bool is_trans = false;
+            V3 raw = unit1;
+            if (bounce) raw = sample_brdf_finish<false>(n, unit1, P.wo, m, draw, cs, sn, is_trans);
+            const V3 unit2 = normalize(raw);
+            if (bounce) {
+                if (is_trans) P.org = add(P.org, scale(2.0f * kEps, P.dir)); /* ray.cpp:1345-1348: dir is still the arriving direction */
+                P.dir = unit2;
+            } else {
+                P.dir = unit1;
+                P.wo = neg(unit2);
+                P.org = ap;
+                P.weight = mk(1, 1, 1);
+                P.primary = true;
+                P.ps = PS_HIT;
+            }
         } else {
-            /* ray.cpp:1233-1246 */
-            ap = sub(add(add(cam_p, scale(aperture * cs, cam_x)), scale(aperture * sn, cam_y)), scale(0.1f, cam_z));
-            raw = sub(focal, ap);
-        }
-        const V3 unit = normalize(raw);
-        if (bounce) {
-            if (is_trans) P.org = add(P.org, scale(2.0f * kEps, P.dir)); /* ray.cpp:1345-1348: dir is still the arriving direction */
-            P.dir = unit;
-        } else {
-            P.dir = unit;
-            P.wo = neg(normalize(P.dir)); /* normalised again (sic) */
-            P.org = ap;
-            P.weight = mk(1, 1, 1);
-            P.primary = true;
-            P.ps = PS_HIT;
+            /* both branches end by normalising a direction (ray.cpp:1158 / :1240): one converged evaluation */
+            V3 raw, ap = mk(0, 0, 0);
+            bool is_trans = false;
+            if (bounce) {
+                raw = sample_brdf_finish<false>(n, normalize(n), P.wo, m, draw, cs, sn, is_trans);
+            } else {
+                /* ray.cpp:1233-1246 */
+                ap = sub(add(add(cam_p, scale(aperture * cs, cam_x)), scale(aperture * sn, cam_y)), scale(0.1f, cam_z));
+                raw = sub(focal, ap);
+            }
+            const V3 unit = normalize(raw);
+            if (bounce) {
+                if (is_trans) P.org = add(P.org, scale(2.0f * kEps, P.dir)); /* ray.cpp:1345-1348: dir is still the arriving direction */
+                P.dir = unit;
+            } else {
+                P.dir = unit;
+                P.wo = neg(normalize(P.dir)); /* normalised again (sic) */
+                P.org = ap;
+                P.weight = mk(1, 1, 1);
+                P.primary = true;
+                P.ps = PS_HIT;
+            }
         }
         return true;
     }
