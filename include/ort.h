@@ -105,6 +105,8 @@ typedef struct {
     /* the reference-compatible loose octree kept beside it (visibility chains + fallback) */
     uint32_t ref_node_count, ref_nonempty_leaves, ref_max_leaf_records;
     uint64_t ref_bytes;
+    /* analytic shapes kept out of the tree and tested outright by every ray (0: all shapes are in the tree) */
+    uint32_t prologue_prims;
 } ort_tree_info;
 
 /* work counters of one render call (device counters).  All zero unless

@@ -256,6 +256,7 @@ int ort_scene_get_tree_info(const ort_scene *s, ort_tree_info *out) {
     out->ref_max_leaf_records = r.max_leaf_records;
     out->ref_bytes = r.nodes.size() * sizeof(ort::DevRefNode) + r.recs.size() * 4 + r.chain_boxes.size() * 16 +
                      (r.tri_chain.size() + r.sphere_chain.size() + r.box_chain.size() + r.cyl_chain.size()) * 8;
+    out->prologue_prims = t.pro_boxes + t.pro_spheres + t.pro_cyls;
     return ORT_OK;
 }
 

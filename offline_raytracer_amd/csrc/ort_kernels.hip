@@ -48,6 +48,7 @@ struct SceneView {
     const float4 *materials;  /* 5 per material (DevMaterial) */
     const uint32_t *light_is_sphere;
     uint32_t light_count;
+    uint32_t pro_boxes, pro_spheres, pro_cyls; /* analytic prologue: every ray tests shapes [0, n) of each kind outright */
     float cam[12];            /* p, x_axis, y_axis, z_axis */
     /* reference-compatible octree (ort_reftree.cpp): visibility chains + exact fallback */
     const float4 *ref_nodes;   /* 3 per node */
@@ -674,7 +675,8 @@ struct Trav {
     V3 inv_d;
 };
 
-ORT_D void begin_ray(const PathState &P, Trav &T, HitState &h) {
+template <bool COUNTERS>
+ORT_D void begin_ray(const SceneView &sv, const PathState &P, Trav &T, HitState &h, Counters &c) {
     /* raycast_top_most_node (ray.cpp:1165-1176): start at the root */
     T.cur = 0;
     T.sp = 0;
@@ -684,6 +686,14 @@ ORT_D void begin_ray(const PathState &P, Trav &T, HitState &h) {
     h.hit_prim = kNoPrim;
     h.phantom_t = __builtin_inff(); /* none yet; compared with <= against best_t (<= FLT_MAX) */
     h.runner_t = __builtin_inff();
+    /* analytic prologue (ort_tree.cpp): the lanes that start a ray now all test the same shape at the same
+       time -- uniform addresses, no divergence -- and enter the triangle tree with best_t already set */
+    for (uint32_t i = 0; i < sv.pro_boxes; ++i)
+        test_prim<COUNTERS, false>(sv, PRIM_BOX, i, P.org, P.dir, T.inv_d, h.best_t, h.hit_n, h.hit_prim, h.phantom_t, h.runner_t, c.tris, c.analytic);
+    for (uint32_t i = 0; i < sv.pro_spheres; ++i)
+        test_prim<COUNTERS, false>(sv, PRIM_SPHERE, i, P.org, P.dir, T.inv_d, h.best_t, h.hit_n, h.hit_prim, h.phantom_t, h.runner_t, c.tris, c.analytic);
+    for (uint32_t i = 0; i < sv.pro_cyls; ++i)
+        test_prim<COUNTERS, false>(sv, PRIM_CYL, i, P.org, P.dir, T.inv_d, h.best_t, h.hit_n, h.hit_prim, h.phantom_t, h.runner_t, c.tris, c.analytic);
 }
 
 /* Closest hit: interruptible ordered DFS, replaces raycast_bvh (ray.cpp:624-822) on the fast tree.
@@ -816,7 +826,7 @@ ORT_D void pt_lane(const SceneView &sv, const RenderView &rv, uint32_t *lds_stac
             if (P.ps == PS_HIT) resolve_hit<COUNTERS>(sv, P.org, P.dir, T.inv_d, lane_id, h, c);
             tracing = produce_ray<COUNTERS, DIFFUSE>(sv, rv, P, h, c, lds_focal + tid, kBlock);
             if (tracing) {
-                begin_ray(P, T, h);
+                begin_ray<COUNTERS>(sv, P, T, h, c);
                 if (COUNTERS) c.rays++;
             }
         }
@@ -877,7 +887,7 @@ ORT_D void wf_trace_slot(const SceneView &sv, const WfView &wf, uint32_t i, uint
     P.org = mk(a.x, a.y, a.z); P.dir = mk(a.w, b.x, b.y);
     HitState h;
     Trav T;
-    begin_ray(P, T, h);
+    begin_ray<COUNTERS>(sv, P, T, h, c);
     traverse<COUNTERS, kWfLdsStack, kBlock>(sv, P.org, P.dir, T, h, lds_stack, spill, tid, 0, 0, c);
     resolve_hit<COUNTERS>(sv, P.org, P.dir, T.inv_d, lane_id, h, c);
     wf.hit0[i] = make_float4(h.best_t, h.hit_n.x, h.hit_n.y, h.hit_n.z);
@@ -1124,7 +1134,12 @@ int device_upload(Scene *scene, int device, std::string *err) {
     ORT_HIP(hipGetDeviceProperties(&prop, device));
     d->cu_count = prop.multiProcessorCount;
     /* persistent grid: 4 workgroups of 256 lanes per CU */
-    d->max_blocks = (unsigned int)(d->cu_count > 0 ? d->cu_count : 256) * 4u;
+    {
+        const char *e = getenv("ORT_BLOCKS_PER_CU"); /* tuning knob: resident workgroups per CU (4 = one wave per SIMD each) */
+        unsigned int per_cu = e ? (unsigned int)atoi(e) : 4u;
+        if (per_cu < 1u || per_cu > 4u) per_cu = 4u;
+        d->max_blocks = (unsigned int)(d->cu_count > 0 ? d->cu_count : 256) * per_cu;
+    }
     /* fallback queues: one entry per reference-tree node each, as many as fit the budget */
     d->bfs_queue_cap = (uint32_t)rt.nodes.size() + 8u;
     size_t fit = kBfsPoolBytes / ((size_t)d->bfs_queue_cap * sizeof(uint32_t));
@@ -1239,6 +1254,9 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
     sv.materials = (const float4 *)d->materials;
     sv.light_is_sphere = (const uint32_t *)d->light_is_sphere;
     sv.light_count = d->light_count;
+    sv.pro_boxes = scene->tree.pro_boxes;
+    sv.pro_spheres = scene->tree.pro_spheres;
+    sv.pro_cyls = scene->tree.pro_cyls;
     sv.ref_nodes = (const float4 *)d->ref_nodes; sv.ref_recs = (const uint32_t *)d->ref_recs;
     sv.chain_boxes = (const float4 *)d->chain_boxes;
     sv.tri_chain = (const uint32_t *)d->tri_chain; sv.sphere_chain = (const uint32_t *)d->sphere_chain;

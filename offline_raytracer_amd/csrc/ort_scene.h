@@ -90,6 +90,10 @@ struct Tree {
     std::vector<uint32_t> tri_slot, sphere_slot, box_slot, cyl_slot;
     uint32_t leaf_count = 0, max_leaf_prims = 0, max_depth = 0;
     float sah_cost = 0;
+    /* the scene's few analytic shapes are not in the tree: every ray tests all of them up front, the
+       whole wave in step (ort_kernels.hip: start_ray); the tree then holds the triangles only */
+    bool analytic_prologue = false;
+    uint32_t pro_boxes = 0, pro_spheres = 0, pro_cyls = 0; /* shapes [0, n) of each kind form the prologue */
     bool built = false;
 };
 

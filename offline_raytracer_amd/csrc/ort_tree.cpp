@@ -21,6 +21,7 @@
 namespace ort {
 
 namespace {
+constexpr float kPrologueBudget = 10.0f; /* analytic shapes worth up to this many box tests are tested outright (see build_tree) */
 
 struct Box3 {
     float lo[3], hi[3];
@@ -104,6 +105,7 @@ struct Builder {
     uint32_t kMaxLeafTri = 4;   /* tuning knobs (env ORT_LEAF_TRI / ORT_LEAF_OTHER); results do not depend on them */
     uint32_t kMaxLeafOther = 2;
     static constexpr uint32_t kDepthBudget = 60; /* traversal stack holds 64 entries */
+
     static constexpr float kNodeCost = 1.0f, kPrimCost = 1.2f;
     double sah_sum = 0;
     float root_area = 1;
@@ -407,19 +409,51 @@ int build_tree(Scene *scene, std::string *err) {
         const char *split_env = getenv("ORT_TREE_SPLIT_KINDS");
         bool split_kinds = split_env ? atoi(split_env) != 0 : true;
         uint32_t n_analytic = (uint32_t)(std::partition(b.prims.begin(), b.prims.end(), [](const Prim &p) { return p.kind != PRIM_TRI; }) - b.prims.begin());
+        /* A handful of analytic shapes (the room, the lights) is cheaper to test outright, all lanes of a
+           wave on the same shape at the same time, than to reach through tree nodes in divergent lanes:
+           they stay out of the tree and form the ray's prologue (tuned on MI355X, profiles/r01_tuning.md) */
+        const char *pro_env = getenv("ORT_ANALYTIC_PROLOGUE");
+        /* not for trees that leave the L2 (C5, 86 MB): there the launch is bound by the memory system, which
+           collapses when the kernel gets more efficient at full occupancy -- 527 Mpaths/s without the prologue,
+           255 with it at 4 workgroups per CU, 522 with it at 3 (profiles/r01_tuning.md) */
+        const bool cache_resident = (b.prims.size() - n_analytic) * (sizeof(DevTri) + 32u) <= (size_t)(16u << 20);
+        const float pro_budget = pro_env ? (float)atof(pro_env) : (cache_resident ? kPrologueBudget : 0.0f);
+        /* cheapest kinds first (a sphere test costs about 1.5 box tests, a cylinder about 5), as many as fit */
+        auto cost_of = [](const Prim &p) { return p.kind == PRIM_BOX ? 1.0f : p.kind == PRIM_SPHERE ? 1.5f : 5.0f; };
+        std::stable_sort(b.prims.begin(), b.prims.begin() + n_analytic, [&](const Prim &x, const Prim &y) { return cost_of(x) < cost_of(y); });
+        uint32_t n_pro = 0;
+        for (float spent = 0; n_pro < n_analytic && spent + cost_of(b.prims[n_pro]) <= pro_budget; ++n_pro) spent += cost_of(b.prims[n_pro]);
+        tree->analytic_prologue = n_pro > 0;
+        tree->pro_boxes = tree->pro_spheres = tree->pro_cyls = 0;
+        for (uint32_t i = 0; i < n_pro; ++i) { /* into the shape arrays (slots 0.. of each kind), not the tree */
+            (void)b.emit_leaf(i, i + 1);
+            (b.prims[i].kind == PRIM_BOX ? tree->pro_boxes : b.prims[i].kind == PRIM_SPHERE ? tree->pro_spheres : tree->pro_cyls)++;
+        }
+        tree->leaf_count = 0;
+        const uint32_t n_all = (uint32_t)b.prims.size();
         uint32_t root;
-        if (split_kinds && n_analytic > 0 && n_analytic < b.prims.size()) {
+        if (n_pro == n_all) { /* nothing left for the tree */
+            DevNode n{};
+            for (int k = 0; k < 3; ++k) { n.lo0[k] = n.lo1[k] = FLT_MAX; n.hi0[k] = n.hi1[k] = -FLT_MAX; }
+            n.child0 = n.child1 = EMPTY_CHILD;
+            tree->nodes.push_back(n);
+            tree->sah_cost = 0;
+            tree->built = true;
+            return ORT_OK;
+        }
+        all = b.bounds(n_pro, n_all);
+        if (split_kinds && n_analytic > n_pro && n_analytic < n_all) {
             tree->nodes.push_back(DevNode{});
-            Box3 ab = b.bounds(0, n_analytic), tb = b.bounds(n_analytic, (uint32_t)b.prims.size());
-            uint32_t c0 = b.build(0, n_analytic, ab, 1);
-            uint32_t c1 = b.build(n_analytic, (uint32_t)b.prims.size(), tb, 1);
+            Box3 ab = b.bounds(n_pro, n_analytic), tb = b.bounds(n_analytic, n_all);
+            uint32_t c0 = b.build(n_pro, n_analytic, ab, 1);
+            uint32_t c1 = b.build(n_analytic, n_all, tb, 1);
             DevNode &n = tree->nodes[0];
             memcpy(n.lo0, ab.lo, 12); memcpy(n.hi0, ab.hi, 12);
             memcpy(n.lo1, tb.lo, 12); memcpy(n.hi1, tb.hi, 12);
             n.child0 = c0; n.child1 = c1;
             root = (c0 | c1) & SPHERE_BELOW_BIT;
         } else {
-            root = b.build(0, (uint32_t)b.prims.size(), all, 0);
+            root = b.build(n_pro, n_all, all, 0);
         }
         if (!(root & LEAF_BIT) && (root & NODE_INDEX_MASK) != 0) { *err = "internal: root is not node 0"; return ORT_ERR_INVALID; }
         if (root & LEAF_BIT) {

@@ -172,6 +172,8 @@ def test_reference_compatible_octree_counts(manifest, load_scene, name):
 
 def test_fast_tree_shape(load_scene):
     ti = load_scene("c3_bunny_room").tree_info()
+    assert ti["prologue_prims"] == 8  # six room slabs, the table, the light: tested outright, not in the tree
+    assert load_scene("testscene").tree_info()["prologue_prims"] == 9  # its nine boxes; spheres and cylinders stay in the tree
     assert ti["leaf_count"] == ti["node_count"] + 1  # binary tree with leaves encoded in child words
     assert ti["max_leaf_prims"] <= 16
     assert ti["max_depth"] <= 60  # the traversal stack holds 24 (LDS) + 64 (scratch) entries
@@ -187,7 +189,8 @@ def test_empty_and_tiny_scenes_commit(api):
     sph["r"] = 1
     sph["mat"] = 1
     s = api.Scene.from_arrays(mats, spheres=sph).commit()
-    assert s.tree_info()["leaf_count"] == 1
+    ti = s.tree_info()  # a lone analytic shape is tested outright (prologue), the tree stays empty
+    assert ti["prologue_prims"] == 1 and ti["leaf_count"] == 0 and ti["node_count"] == 1
     with pytest.raises(api.OrtError):
         bad = sph.copy()
         bad["mat"] = 7

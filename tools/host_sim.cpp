@@ -52,6 +52,7 @@ int main(int argc, char **argv) {
     sv.cyls = (const float4 *)t.cyls.data(); sv.cyl_mat = t.cyl_mat.data();
     sv.materials = (const float4 *)mats.data();
     sv.light_is_sphere = lis.data(); sv.light_count = (uint32_t)lis.size();
+    sv.pro_boxes = t.pro_boxes; sv.pro_spheres = t.pro_spheres; sv.pro_cyls = t.pro_cyls;
     const RefTree &rt = scene->ref;
     sv.ref_nodes = (const float4 *)rt.nodes.data(); sv.ref_recs = rt.recs.data(); sv.chain_boxes = (const float4 *)rt.chain_boxes.data();
     sv.tri_chain = rt.tri_chain.data(); sv.sphere_chain = rt.sphere_chain.data(); sv.box_chain = rt.box_chain.data(); sv.cyl_chain = rt.cyl_chain.data();
