@@ -181,6 +181,9 @@ enum : int { PS_NEED_JOB = 0, PS_PIXEL = 1, PS_SAMPLE = 2, PS_HIT = 3, PS_DONE =
 #ifndef ORT_TRAV_WHILEWHILE
 #define ORT_TRAV_WHILEWHILE 1
 #endif
+#ifndef ORT_DESCEND_SHIFT
+#define ORT_DESCEND_SHIFT 2
+#endif
 
 constexpr uint32_t kNoPrim = 0xffffffffu;
 constexpr uint32_t kTraversalDone = 0xffffffffu; /* == EMPTY_CHILD: a leaf word no tree contains */
@@ -718,6 +721,10 @@ ORT_D bool traverse(const SceneView &sv, V3 org, V3 dir, Trav &T, HitState &h, u
     const V3 inv_d = T.inv_d;
     while (tracing) {
         ORT_UTIL(sv, 2, true);
+        /* the straggler threshold of this round: descend_below, but never more than a quarter of the lanes
+           that start descending now (a wave that enters with 20 such lanes should not stop at 8) */
+        const int entering = ORT_POPC64(ORT_BALLOT((cur & LEAF_BIT) == 0u));
+        const int stragglers = descend_below < (entering >> ORT_DESCEND_SHIFT) ? descend_below : (entering >> ORT_DESCEND_SHIFT);
 #if ORT_TRAV_WHILEWHILE
         while (!(cur & LEAF_BIT)) {
 #else
@@ -765,7 +772,7 @@ ORT_D bool traverse(const SceneView &sv, V3 org, V3 dir, Trav &T, HitState &h, u
 #if ORT_TRAV_WHILEWHILE
             /* the stragglers of the descend loop would keep the rest of the wave waiting: break out
                and come back for them (their cur / sp carry over) */
-            if (ORT_POPC64(ORT_BALLOT(true)) < descend_below) break;
+            if (ORT_POPC64(ORT_BALLOT(true)) < stragglers) break;
 #endif
         }
 #if ORT_TRAV_WHILEWHILE
