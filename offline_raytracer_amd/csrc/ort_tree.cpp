@@ -420,7 +420,10 @@ int build_tree(Scene *scene, std::string *err) {
         const float pro_budget = pro_env ? (float)atof(pro_env) : (cache_resident ? kPrologueBudget : 0.0f);
         /* cheapest kinds first (a sphere test costs about 1.5 box tests, a cylinder about 5), as many as fit */
         auto cost_of = [](const Prim &p) { return p.kind == PRIM_BOX ? 1.0f : p.kind == PRIM_SPHERE ? 1.5f : 5.0f; };
-        std::stable_sort(b.prims.begin(), b.prims.begin() + n_analytic, [&](const Prim &x, const Prim &y) { return cost_of(x) < cost_of(y); });
+        /* within a kind the largest shapes first: they are the ones most rays hit */
+        std::stable_sort(b.prims.begin(), b.prims.begin() + n_analytic, [&](const Prim &x, const Prim &y) {
+            return cost_of(x) != cost_of(y) ? cost_of(x) < cost_of(y) : x.box.half_area() > y.box.half_area();
+        });
         uint32_t n_pro = 0;
         for (float spent = 0; n_pro < n_analytic && spent + cost_of(b.prims[n_pro]) <= pro_budget; ++n_pro) spent += cost_of(b.prims[n_pro]);
         tree->analytic_prologue = n_pro > 0;
