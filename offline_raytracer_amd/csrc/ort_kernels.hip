@@ -197,10 +197,12 @@ ORT_D uint32_t prim_order(const SceneView &sv, uint32_t kind, uint32_t slot) {
    accept when hit_t >= 1e-6 and strictly closer than the best so far */
 template <bool COUNTERS, bool EXACT_ORDER>
 ORT_D void test_prim(const SceneView &sv, uint32_t kind, uint32_t slot, V3 org, V3 dir, V3 inv_d, float &best_t, V3 &hit_n,
-                     uint32_t &hit_prim, float &phantom_t, float &runner_t, unsigned long long &c_tris, unsigned long long &c_analytic) {
+                     uint32_t &hit_prim, float &phantom_t, float &runner_t, unsigned long long &c_tris, unsigned long long &c_analytic,
+                     uint32_t excl = 0xffffffffu) {
     float t;
     V3 n = mk(0, 0, 0);
     bool tangent = false;
+    if (!EXACT_ORDER && ((kind << 28) | slot) == excl) return;
     if (kind == PRIM_TRI) {
         const float4 *tp = sv.tris + 3u * slot;
         float4 a = tp[0], b = tp[1], c = tp[2];
@@ -254,18 +256,25 @@ ORT_D void test_prim(const SceneView &sv, uint32_t kind, uint32_t slot, V3 org, 
    t_other is the nearest other hit (runner-up or phantom), exact within 2e-4 of t_hit because the fast
    traversal tests everything in that window; an entry below t_other (and inside the window) is below
    any best the reference can have held.  Otherwise undecidable here: the caller re-casts exactly. */
-ORT_D bool ref_node_admits(V3 lo, V3 hi, V3 org, V3 inv_d, float t_hit, float t_other) {
-    if ((org.x >= lo.x && org.x < hi.x) && (org.y >= lo.y && org.y < hi.y) && (org.z >= lo.z && org.z < hi.z)) return true;
+enum : int { CH_ADMIT = 0, CH_REJECT = 1, CH_UNKNOWN = 2 };
+/* CH_REJECT: never admitted whatever was found before (the ray misses the box or enters below 1e-6 from
+   outside): the shapes below are invisible to this ray.  CH_UNKNOWN: enters at t_entry > t_hit with another
+   hit possibly in between; t_entry is handed back in gap */
+ORT_D int ref_node_verdict(V3 lo, V3 hi, V3 org, V3 inv_d, float t_hit, float t_other, float &gap) {
+    if ((org.x >= lo.x && org.x < hi.x) && (org.y >= lo.y && org.y < hi.y) && (org.z >= lo.z && org.z < hi.z)) return CH_ADMIT;
     const float t = hit_aab_t(lo, hi, org, inv_d);
-    return t >= kHitTMin && (t <= t_hit || (t < t_other && t < t_hit * 1.0001f));
+    if (!(t >= kHitTMin)) return CH_REJECT;
+    if (t <= t_hit || (t < t_other && t < t_hit * 1.0001f)) return CH_ADMIT;
+    gap = fmaxf(gap, t);
+    return CH_UNKNOWN;
 }
 
 /* would the reference have reached this primitive?  Every node box on the way down must admit the
    ray (origin inside, half-open; or entered at t >= 1e-6).  Entries run from the primitive's own node
-   (entry 0, the smallest box) up to the root's child.  chain_admits_full tests them all, four at a
+   (entry 0, the smallest box) up to the root's child.  chain_verdict_full tests them all, four at a
    time so the (divergent, L2-latency-bound) loads overlap. */
-ORT_D bool chain_admits_full(const SceneView &sv, uint32_t first, uint32_t len, V3 org, V3 inv_d, float t_hit, float t_other) {
-    bool ok = true;
+ORT_D int chain_verdict_full(const SceneView &sv, uint32_t first, uint32_t len, V3 org, V3 inv_d, float t_hit, float t_other, float &gap) {
+    int verdict = CH_ADMIT;
     for (uint32_t base = 0; base < len; base += 4u) {
         float4 lo[4], hi[4];
 #pragma unroll
@@ -276,11 +285,13 @@ ORT_D bool chain_admits_full(const SceneView &sv, uint32_t first, uint32_t len, 
             hi[k] = sv.chain_boxes[2u * (first + i) + 1u];
         }
 #pragma unroll
-        for (uint32_t k = 0; k < 4u; ++k)
-            ok = ok && ref_node_admits(mk(lo[k].x, lo[k].y, lo[k].z), mk(hi[k].x, hi[k].y, hi[k].z), org, inv_d, t_hit, t_other);
-        if (!ok) break;
+        for (uint32_t k = 0; k < 4u; ++k) {
+            const int v = ref_node_verdict(mk(lo[k].x, lo[k].y, lo[k].z), mk(hi[k].x, hi[k].y, hi[k].z), org, inv_d, t_hit, t_other, gap);
+            verdict = (v == CH_REJECT || verdict == CH_REJECT) ? CH_REJECT : (v == CH_UNKNOWN ? CH_UNKNOWN : verdict);
+        }
+        if (verdict == CH_REJECT) break;
     }
-    return ok;
+    return verdict;
 }
 
 ORT_D bool in_rect_half_open(float4 lo, float4 hi, V3 org) { /* math.h:1156-1169 */
@@ -299,16 +310,17 @@ constexpr uint32_t kChainNested = 0x08000000u;
 #if defined(ORT_HOST_SIM) && defined(ORT_CHAIN_CROSSCHECK)
 static unsigned long long g_chain_crosschecks = 0;
 #endif
-ORT_D bool chain_admits(const SceneView &sv, uint32_t prim, V3 org, V3 inv_d, float t_hit, float t_other) {
+ORT_D int chain_verdict(const SceneView &sv, uint32_t prim, V3 org, V3 inv_d, float t_hit, float t_other, float &gap) {
     uint32_t kind = prim >> 28, slot = prim & 0x00ffffffu;
     uint32_t word = (kind == PRIM_TRI) ? sv.tri_chain[slot]
                   : (kind == PRIM_SPHERE) ? sv.sphere_chain[slot]
                   : (kind == PRIM_BOX) ? sv.box_chain[slot] : sv.cyl_chain[slot];
     const uint32_t len = word >> 28, first = word & 0x07ffffffu;
-    if (len == 0u) return true;
+    gap = 0.0f;
+    if (len == 0u) return CH_ADMIT;
     const bool finite = (om_f32_bits(inv_d.x) & 0x7fffffffu) < 0x7f800000u && (om_f32_bits(inv_d.y) & 0x7fffffffu) < 0x7f800000u &&
                         (om_f32_bits(inv_d.z) & 0x7fffffffu) < 0x7f800000u;
-    if (!(word & kChainNested) || !finite) return chain_admits_full(sv, first, len, org, inv_d, t_hit, t_other);
+    if (!(word & kChainNested) || !finite) return chain_verdict_full(sv, first, len, org, inv_d, t_hit, t_other, gap);
     const float4 dlo = sv.chain_boxes[2u * first], dhi = sv.chain_boxes[2u * first + 1u];
     float4 jlo = dlo, jhi = dhi;
     bool found = false;
@@ -330,15 +342,22 @@ ORT_D bool chain_admits(const SceneView &sv, uint32_t prim, V3 org, V3 inv_d, fl
             if (!found && outside) { jlo = lo[k]; jhi = hi[k]; found = true; }
         }
     }
-    /* !found: the origin is inside every box of the chain */
-    /* the entry distance only grows down the chain: the upper bound needs checking at the leaf box alone */
-    const bool admits = !found || (hit_aab_t(mk(jlo.x, jlo.y, jlo.z), mk(jhi.x, jhi.y, jhi.z), org, inv_d) >= kHitTMin &&
-                                   ref_node_admits(mk(dlo.x, dlo.y, dlo.z), mk(dhi.x, dhi.y, dhi.z), org, inv_d, t_hit, t_other));
+    /* !found: the origin is inside every box of the chain.  Otherwise the first box from the top that does not
+       contain the origin must be entered at t >= 1e-6, and the leaf box decides the rest: the entry distance
+       only grows down the chain */
+    int verdict = CH_ADMIT;
+    if (found) {
+        const float tj = hit_aab_t(mk(jlo.x, jlo.y, jlo.z), mk(jhi.x, jhi.y, jhi.z), org, inv_d);
+        verdict = !(tj >= kHitTMin) ? CH_REJECT : ref_node_verdict(mk(dlo.x, dlo.y, dlo.z), mk(dhi.x, dhi.y, dhi.z), org, inv_d, t_hit, t_other, gap);
+    }
 #if defined(ORT_HOST_SIM) && defined(ORT_CHAIN_CROSSCHECK) /* tools/host_sim: the shortcut against the full walk, every ray */
-    if (admits != chain_admits_full(sv, first, len, org, inv_d, t_hit, t_other)) { fprintf(stderr, "chain shortcut disagrees with the full walk\n"); abort(); }
-    g_chain_crosschecks++;
+    {
+        float g2 = 0.0f;
+        if (verdict != chain_verdict_full(sv, first, len, org, inv_d, t_hit, t_other, g2)) { fprintf(stderr, "chain shortcut disagrees with the full walk\n"); abort(); }
+        g_chain_crosschecks++;
+    }
 #endif
-    return admits;
+    return verdict;
 }
 
 /* exact fallback: raycast_bvh (ray.cpp:624-822) emulated literally on the reference-compatible
@@ -429,17 +448,40 @@ ORT_D float *job_plane(const RenderView &rv, uint32_t plane) {
     return (rv.mode == JOBS_CHUNK) ? rv.partial + (size_t)plane * (size_t)rv.W * (size_t)rv.H * 3u : rv.out;
 }
 
-/* After a traversal: would the reference have seen this winner (ray.cpp:788-803)?  If not, or if a
-   phantom tangent hit could have won, re-cast the ray exactly. */
+/* traversal state of one ray on the fast tree */
+struct Trav {
+    uint32_t cur = 0;
+    int sp = 0;
+    V3 inv_d;
+};
+
+ORT_D void reset_hit(HitState &h, float best_t) {
+    h.best_t = best_t;
+    h.hit_n = mk(0, 0, 0);
+    h.hit_prim = kNoPrim;
+    h.phantom_t = __builtin_inff(); /* none yet; compared with <= against best_t (<= FLT_MAX) */
+    h.runner_t = __builtin_inff();
+}
+
+/* the analytic prologue (ort_tree.cpp): the lanes that start a ray now all test the same shape at the same
+   time -- uniform addresses, no divergence -- and enter the tree with best_t already set */
 template <bool COUNTERS>
-ORT_D void resolve_hit(const SceneView &sv, V3 org, V3 dir, V3 inv_d, uint32_t lane_id, HitState &h, Counters &c) {
-    const bool need = (h.hit_prim != kNoPrim && !chain_admits(sv, h.hit_prim, org, inv_d, h.best_t, fminf(h.runner_t, h.phantom_t))) || h.phantom_t <= h.best_t ||
-                      (sv.force_fallback_mask != 0xffffffffu && (om_f32_bits(dir.x) & sv.force_fallback_mask) == 0u);
-    /* Rare.  The lanes of a wave that need the re-cast take turns (wave-uniform loop over the ballot), so
-       a wave never has more than one lane holding or waiting for a queue of the pool: a waiting lane can
-       only wait for holders in other waves, which are running, never for a lane of its own wave parked at a
-       reconvergence point.  The fences order the queue's contents across holders on different XCDs
-       (each XCD has its own L2). */
+ORT_D void prologue_tests(const SceneView &sv, V3 org, V3 dir, V3 inv_d, HitState &h, Counters &c, uint32_t excl = kNoPrim) {
+    for (uint32_t i = 0; i < sv.pro_boxes; ++i)
+        test_prim<COUNTERS, false>(sv, PRIM_BOX, i, org, dir, inv_d, h.best_t, h.hit_n, h.hit_prim, h.phantom_t, h.runner_t, c.tris, c.analytic, excl);
+    for (uint32_t i = 0; i < sv.pro_spheres; ++i)
+        test_prim<COUNTERS, false>(sv, PRIM_SPHERE, i, org, dir, inv_d, h.best_t, h.hit_n, h.hit_prim, h.phantom_t, h.runner_t, c.tris, c.analytic, excl);
+    for (uint32_t i = 0; i < sv.pro_cyls; ++i)
+        test_prim<COUNTERS, false>(sv, PRIM_CYL, i, org, dir, inv_d, h.best_t, h.hit_n, h.hit_prim, h.phantom_t, h.runner_t, c.tris, c.analytic, excl);
+}
+
+/* the exact answer: raycast_bvh emulated literally on the reference-compatible octree.  Rare.  The lanes of a
+   wave that need it take turns (wave-uniform loop over the ballot), so a wave never has more than one lane
+   holding or waiting for a queue of the pool: a waiting lane can only wait for holders in other waves, which
+   are running, never for a lane of its own wave parked at a reconvergence point.  The fences order the queue's
+   contents across holders on different XCDs (each XCD has its own L2). */
+template <bool COUNTERS>
+ORT_D void recast_exactly(const SceneView &sv, bool need, V3 org, V3 dir, V3 inv_d, uint32_t lane_id, HitState &h, Counters &c) {
     unsigned long long pending = ORT_BALLOT(need);
     while (pending) {
         const int leader = ORT_FFS64(pending) - 1;
@@ -671,12 +713,6 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderView &rv, PathState &P, 
     return false;
 }
 
-/* traversal state of one ray on the fast tree */
-struct Trav {
-    uint32_t cur = 0;
-    int sp = 0;
-    V3 inv_d;
-};
 
 template <bool COUNTERS>
 ORT_D void begin_ray(const SceneView &sv, const PathState &P, Trav &T, HitState &h, Counters &c) {
@@ -684,19 +720,8 @@ ORT_D void begin_ray(const SceneView &sv, const PathState &P, Trav &T, HitState 
     T.cur = 0;
     T.sp = 0;
     T.inv_d = mk(1.0f / P.dir.x, 1.0f / P.dir.y, 1.0f / P.dir.z); /* ray.cpp:210, once per ray */
-    h.best_t = 3.402823466e+38f; /* Flt_Max, ray.cpp:627 */
-    h.hit_n = mk(0, 0, 0);
-    h.hit_prim = kNoPrim;
-    h.phantom_t = __builtin_inff(); /* none yet; compared with <= against best_t (<= FLT_MAX) */
-    h.runner_t = __builtin_inff();
-    /* analytic prologue (ort_tree.cpp): the lanes that start a ray now all test the same shape at the same
-       time -- uniform addresses, no divergence -- and enter the triangle tree with best_t already set */
-    for (uint32_t i = 0; i < sv.pro_boxes; ++i)
-        test_prim<COUNTERS, false>(sv, PRIM_BOX, i, P.org, P.dir, T.inv_d, h.best_t, h.hit_n, h.hit_prim, h.phantom_t, h.runner_t, c.tris, c.analytic);
-    for (uint32_t i = 0; i < sv.pro_spheres; ++i)
-        test_prim<COUNTERS, false>(sv, PRIM_SPHERE, i, P.org, P.dir, T.inv_d, h.best_t, h.hit_n, h.hit_prim, h.phantom_t, h.runner_t, c.tris, c.analytic);
-    for (uint32_t i = 0; i < sv.pro_cyls; ++i)
-        test_prim<COUNTERS, false>(sv, PRIM_CYL, i, P.org, P.dir, T.inv_d, h.best_t, h.hit_n, h.hit_prim, h.phantom_t, h.runner_t, c.tris, c.analytic);
+    reset_hit(h, 3.402823466e+38f); /* Flt_Max, ray.cpp:627 */
+    prologue_tests<COUNTERS>(sv, P.org, P.dir, T.inv_d, h, c);
 }
 
 /* Closest hit: interruptible ordered DFS, replaces raycast_bvh (ray.cpp:624-822) on the fast tree.
@@ -714,7 +739,7 @@ constexpr float kCullSlack = 0.9997996f; /* <= 0.9999996 / 1.0002 */
 
 template <bool COUNTERS, int LDS_ENTRIES, int BLOCK>
 ORT_D bool traverse(const SceneView &sv, V3 org, V3 dir, Trav &T, HitState &h, uint32_t *lds_stack, uint32_t *spill, int tid,
-                    int refill_below, int descend_below, Counters &c) {
+                    int refill_below, int descend_below, Counters &c, uint32_t excl = kNoPrim) {
     bool tracing = true;
     uint32_t cur = T.cur;
     int sp = T.sp;
@@ -787,7 +812,7 @@ ORT_D bool traverse(const SceneView &sv, V3 org, V3 dir, Trav &T, HitState &h, u
             ORT_UTIL(sv, 1, true);
             uint32_t kind = (cur >> 28) & 7u, count = ((cur >> 24) & 15u) + 1u, first = cur & 0x00ffffffu;
             for (uint32_t i = 0; i < count; ++i)
-                test_prim<COUNTERS, false>(sv, kind, first + i, org, dir, inv_d, h.best_t, h.hit_n, h.hit_prim, h.phantom_t, h.runner_t, c.tris, c.analytic);
+                test_prim<COUNTERS, false>(sv, kind, first + i, org, dir, inv_d, h.best_t, h.hit_n, h.hit_prim, h.phantom_t, h.runner_t, c.tris, c.analytic, excl);
             if (sp == 0) {
                 cur = kTraversalDone;
                 tracing = false;
@@ -805,6 +830,66 @@ ORT_D bool traverse(const SceneView &sv, V3 org, V3 dir, Trav &T, HitState &h, u
     T.cur = cur;
     T.sp = sp;
     return tracing;
+}
+
+/* After a traversal: is the winner W of the fast traversal what the reference returns (ray.cpp:788-803)?
+
+   - W's chain admits the ray (chain_verdict): done.
+   - A box of W's chain can never be entered (CH_REJECT: missed, or entered below 1e-6 from outside --
+     the reference's cylinder boxes do not contain their cylinders): W is invisible to this ray whatever the
+     visiting order, so the answer is the best of the OTHER shapes: one more fast traversal with W ignored,
+     whose winner is checked the same way.
+   - W's leaf box is entered beyond W's own distance with room for another hit in between (CH_UNKNOWN): one
+     more fast traversal, limited to that entry distance and ignoring W, settles whether such a hit exists;
+     if not, W stands.
+   - Anything else (a phantom that could win, a second complication on the same ray): the literal
+     breadth-first emulation.
+   The extra traversals run here, to completion, for the lanes that need them (1e-5 of the rays of the
+   reference's scenes, 1e-2 with slanted cylinders) while the rest of the wave waits: the shape to ignore is
+   a local of this rare branch, not a register carried through every ray's traversal. */
+template <bool COUNTERS, int LDS_ENTRIES, int BLOCK>
+ORT_D void resolve_hit(const SceneView &sv, V3 org, V3 dir, V3 inv_d, uint32_t lane_id, HitState &h, Counters &c, uint32_t *lds_stack,
+                       uint32_t *spill, int tid) {
+    bool recast = sv.force_fallback_mask != 0xffffffffu && (om_f32_bits(dir.x) & sv.force_fallback_mask) == 0u;
+    if (!recast) {
+        if (h.phantom_t <= h.best_t) {
+            recast = true;
+        } else if (h.hit_prim != kNoPrim) {
+            float gap = 0.0f;
+            const int verdict = chain_verdict(sv, h.hit_prim, org, inv_d, h.best_t, fminf(h.runner_t, h.phantom_t), gap);
+            if (verdict != CH_ADMIT) {
+                /* W waits in the lane's (idle) traversal-stack slots of LDS, not in registers */
+                const uint32_t w_prim = h.hit_prim;
+                uint32_t *save = lds_stack + tid;
+                save[(LDS_ENTRIES - 1) * BLOCK] = om_f32_bits(h.best_t);
+                save[(LDS_ENTRIES - 2) * BLOCK] = om_f32_bits(h.hit_n.x);
+                save[(LDS_ENTRIES - 3) * BLOCK] = om_f32_bits(h.hit_n.y);
+                save[(LDS_ENTRIES - 4) * BLOCK] = om_f32_bits(h.hit_n.z);
+                Trav t2;
+                t2.cur = 0; t2.sp = 0; t2.inv_d = inv_d;
+                /* CH_UNKNOWN: only hits at or before the leaf box's entry matter (the hit tests' "<" must accept t == gap) */
+                reset_hit(h, verdict == CH_REJECT ? 3.402823466e+38f : om_bits_f32(om_f32_bits(gap) + 1u));
+                prologue_tests<COUNTERS>(sv, org, dir, inv_d, h, c, w_prim);
+                (void)traverse<COUNTERS, LDS_ENTRIES - 4, BLOCK>(sv, org, dir, t2, h, lds_stack, spill, tid, 0, 0, c, w_prim);
+                if (verdict == CH_UNKNOWN) {
+                    if (h.hit_prim != kNoPrim || h.phantom_t <= gap) {
+                        recast = true; /* something is there: order decides */
+                    } else {           /* nothing there: W stands */
+                        h.best_t = om_bits_f32(save[(LDS_ENTRIES - 1) * BLOCK]);
+                        h.hit_n = mk(om_bits_f32(save[(LDS_ENTRIES - 2) * BLOCK]), om_bits_f32(save[(LDS_ENTRIES - 3) * BLOCK]),
+                                     om_bits_f32(save[(LDS_ENTRIES - 4) * BLOCK]));
+                        h.hit_prim = w_prim;
+                    }
+                } else if (h.phantom_t <= h.best_t) {
+                    recast = true;
+                } else if (h.hit_prim != kNoPrim) {
+                    float gap2 = 0.0f;
+                    if (chain_verdict(sv, h.hit_prim, org, inv_d, h.best_t, fminf(h.runner_t, h.phantom_t), gap2) != CH_ADMIT) recast = true;
+                }
+            }
+        }
+    }
+    recast_exactly<COUNTERS>(sv, recast, org, dir, inv_d, lane_id, h, c);
 }
 
 ORT_D void flush_counters(const RenderView &rv, const Counters &c, bool all) {
@@ -830,7 +915,7 @@ ORT_D void pt_lane(const SceneView &sv, const RenderView &rv, uint32_t *lds_stac
         if (!tracing) {
             ORT_UTIL(sv, 3, true);
             ORT_UTIL(sv, 4, P.ps == PS_HIT);
-            if (P.ps == PS_HIT) resolve_hit<COUNTERS>(sv, P.org, P.dir, T.inv_d, lane_id, h, c);
+            if (P.ps == PS_HIT) resolve_hit<COUNTERS, kLdsStack, kBlock>(sv, P.org, P.dir, T.inv_d, lane_id, h, c, lds_stack, spill, tid);
             tracing = produce_ray<COUNTERS, DIFFUSE>(sv, rv, P, h, c, lds_focal + tid, kBlock);
             if (tracing) {
                 begin_ray<COUNTERS>(sv, P, T, h, c);
@@ -896,7 +981,7 @@ ORT_D void wf_trace_slot(const SceneView &sv, const WfView &wf, uint32_t i, uint
     Trav T;
     begin_ray<COUNTERS>(sv, P, T, h, c);
     traverse<COUNTERS, kWfLdsStack, kBlock>(sv, P.org, P.dir, T, h, lds_stack, spill, tid, 0, 0, c);
-    resolve_hit<COUNTERS>(sv, P.org, P.dir, T.inv_d, lane_id, h, c);
+    resolve_hit<COUNTERS, kWfLdsStack, kBlock>(sv, P.org, P.dir, T.inv_d, lane_id, h, c, lds_stack, spill, tid);
     wf.hit0[i] = make_float4(h.best_t, h.hit_n.x, h.hit_n.y, h.hit_n.z);
     wf.hitp[i] = h.hit_prim;
 }
