@@ -327,12 +327,13 @@ ORT_D int chain_verdict(const SceneView &sv, uint32_t prim, V3 org, V3 inv_d, fl
 #ifndef ORT_CHAIN_ROUND
 #define ORT_CHAIN_ROUND 2 /* boxes fetched per step from the top (2: 2210, 3: 2183, 4: 2166 Mpaths/s on the bunny room) */
 #endif
-    for (int32_t top = (int32_t)len - 1; !found && top >= 0; top -= ORT_CHAIN_ROUND) {
+    /* the ancestors of the leaf box, from the top: entries len-1 .. 1 (none when the leaf hangs off the root's child) */
+    for (int32_t top = (int32_t)len - 1; !found && top >= 1; top -= ORT_CHAIN_ROUND) {
         float4 lo[ORT_CHAIN_ROUND], hi[ORT_CHAIN_ROUND];
 #pragma unroll
         for (int32_t k = 0; k < ORT_CHAIN_ROUND; ++k) {
             int32_t i = top - k;
-            i = (i > 0) ? i : 0; /* clamp: re-tests entry 0, harmless */
+            i = (i > 1) ? i : 1; /* clamp: re-tests entry 1, harmless */
             lo[k] = sv.chain_boxes[2u * (first + (uint32_t)i)];
             hi[k] = sv.chain_boxes[2u * (first + (uint32_t)i) + 1u];
         }
@@ -342,14 +343,12 @@ ORT_D int chain_verdict(const SceneView &sv, uint32_t prim, V3 org, V3 inv_d, fl
             if (!found && outside) { jlo = lo[k]; jhi = hi[k]; found = true; }
         }
     }
-    /* !found: the origin is inside every box of the chain.  Otherwise the first box from the top that does not
-       contain the origin must be entered at t >= 1e-6, and the leaf box decides the rest: the entry distance
-       only grows down the chain */
+    /* found: an ancestor that does not contain the origin must be entered at t >= 1e-6.  Then, and when every
+       ancestor contains the origin, the leaf box decides the rest (origin inside it, or the bounds on its entry
+       distance): the entry distance only grows down the chain */
     int verdict = CH_ADMIT;
-    if (found) {
-        const float tj = hit_aab_t(mk(jlo.x, jlo.y, jlo.z), mk(jhi.x, jhi.y, jhi.z), org, inv_d);
-        verdict = !(tj >= kHitTMin) ? CH_REJECT : ref_node_verdict(mk(dlo.x, dlo.y, dlo.z), mk(dhi.x, dhi.y, dhi.z), org, inv_d, t_hit, t_other, gap);
-    }
+    if (found && !(hit_aab_t(mk(jlo.x, jlo.y, jlo.z), mk(jhi.x, jhi.y, jhi.z), org, inv_d) >= kHitTMin)) verdict = CH_REJECT;
+    else verdict = ref_node_verdict(mk(dlo.x, dlo.y, dlo.z), mk(dhi.x, dhi.y, dhi.z), org, inv_d, t_hit, t_other, gap);
 #if defined(ORT_HOST_SIM) && defined(ORT_CHAIN_CROSSCHECK) /* tools/host_sim: the shortcut against the full walk, every ray */
     {
         float g2 = 0.0f;
