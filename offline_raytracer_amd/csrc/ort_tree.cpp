@@ -376,6 +376,34 @@ int build_tree(Scene *scene, std::string *err) {
         }
         b.prims.push_back(p);
     }
+    /* The reference's sphere and cylinder intersectors solve their quadratics in f32: the discriminant
+       b^2 - a c cancels, and what they report is the exact hit on a shape whose squared radius is off by up to a
+       few ulps of |origin - shape|^2 -- at 21 units from an r = 0.05 cylinder a "hit" 2.8e-4 outside it was seen
+       (tools/stress_parity.py, testscene, seed 150229).  The fast tree's boxes must contain every hit the
+       intersector can REPORT, so quadric boxes grow to the radius sqrt(r^2 + 16 * 2^-23 * D^2), D = the farthest a ray
+       origin can be (diagonal of everything in the scene and the camera), plus the same bound linearly for the
+       cap planes. */
+    {
+        Box3 all;
+        all.reset();
+        for (const Prim &p : b.prims) all.grow(p.box);
+        const float cam[3] = {scene->camera_p.x, scene->camera_p.y, scene->camera_p.z};
+        all.grow_point(cam);
+        float d2 = 0;
+        for (int k = 0; k < 3; ++k) { float e = all.hi[k] - all.lo[k] + 0.5f; d2 += e * e; }
+        const float slack2 = 16.0f * 1.1920929e-7f * d2, slack1 = 16.0f * 1.1920929e-7f * sqrtf(d2);
+        for (Prim &p : b.prims) {
+            if (p.kind == PRIM_SPHERE) {
+                const ort_sphere &sp = scene->spheres[p.index];
+                const float r0 = sqrtf(sp.r * sp.r + 0.00001f), r1 = sqrtf(sp.r * sp.r + 0.00001f + slack2);
+                for (int k = 0; k < 3; ++k) { p.box.lo[k] -= (r1 - r0) * 1.0001f + slack1; p.box.hi[k] += (r1 - r0) * 1.0001f + slack1; }
+            } else if (p.kind == PRIM_CYL) {
+                const ort_cylinder &c = scene->cylinders[p.index];
+                const float r0 = fabsf(c.r), r1 = sqrtf(c.r * c.r + slack2);
+                for (int k = 0; k < 3; ++k) { p.box.lo[k] -= (r1 - r0) * 1.0002f + slack1; p.box.hi[k] += (r1 - r0) * 1.0002f + slack1; }
+            }
+        }
+    }
     for (Prim &p : b.prims) {
         pad_box(&p.box);
         for (int k = 0; k < 3; ++k) {

@@ -244,6 +244,19 @@ def test_hits_in_front_of_their_node_box(api, oracle, gpu_scene, name, w, h, spp
     assert_bits_equal(img[rect[1]:rect[3], rect[0]:rect[2]], ref[rect[1]:rect[3], rect[0]:rect[2]], name)
 
 
+def test_quadric_hits_reported_outside_the_shape(api, oracle, gpu_scene):
+    """found by tools/stress_parity.py (testscene, rr 0.95, seed 150229): 21 units from an r = 0.05 cylinder the
+    reference's f32 quadratic reports a hit 2.8e-4 OUTSIDE the cylinder, on a ray that misses a tight box around
+    it.  The fast tree's sphere and cylinder boxes therefore carry the intersector's error bound
+    (ort_tree.cpp); this is the pixel that differed."""
+    scene = gpu_scene("testscene")
+    w, h, spp, seed, rr = 256, 144, 16, 150229, 0.95
+    rect = (200, 100, 218, 115)
+    img, _ = scene.render(w, h, spp, seed, "chunk", chunk=8, rect=rect, rr=rr)
+    ref, _ = oracle.OracleScene(scene.flatten(w, h)).render(w, h, spp, seed, "chunk", chunk=8, rect=rect, rr=rr, threads=16)
+    assert_bits_equal(img[rect[1]:rect[3], rect[0]:rect[2]], ref[rect[1]:rect[3], rect[0]:rect[2]])
+
+
 def test_slanted_cylinders_are_settled_without_the_breadth_first_walk(api, oracle, gpu_scene):
     """rand_b holds cylinders with oblique axes, whose reference node boxes (r * (1 - |a_k|/|a|) per axis) leave
     much of the cylinder outside: 0.8 % of all rays hit a cylinder in front of, or entirely outside, its box.

@@ -66,7 +66,7 @@ int main(int argc, char **argv) {
     unsigned long long ctrl[8] = {0};
     RenderView rv{};
     rv.W = W; rv.H = H; rv.x0 = 0; rv.y0 = 0; rv.x1 = W; rv.y1 = H;
-    rv.seed = seed; rv.spp = spp; rv.chunk = chunk; rv.rr = 0.8f;
+    rv.seed = seed; rv.spp = spp; rv.chunk = chunk; rv.rr = getenv("SIM_RR") ? (float)atof(getenv("SIM_RR")) : 0.8f;
     rv.refill_below = 12;
     rv.descend_below = getenv("SIM_DESCEND_BELOW") ? atoi(getenv("SIM_DESCEND_BELOW")) : 8;
     rv.out = out.data(); rv.next_job = ctrl; rv.counters = ctrl + 1;
