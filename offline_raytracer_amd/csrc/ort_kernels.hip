@@ -146,6 +146,7 @@ enum : int { PS_NEED_JOB = 0, PS_PIXEL = 1, PS_SAMPLE = 2, PS_HIT = 3, PS_DONE =
 #define ORT_FFS64(m) __builtin_ffsll((long long)(m))
 #define ORT_LANE() 0
 #define ORT_UTIL(sv, k, pred)
+#define ORT_PHASE(pr, sv, k, pred)
 #ifndef ORT_SIM_PIXEL_HOOK
 #define ORT_SIM_PIXEL_HOOK(x, y, rng)
 #endif
@@ -164,19 +165,41 @@ enum : int { PS_NEED_JOB = 0, PS_PIXEL = 1, PS_SAMPLE = 2, PS_HIT = 3, PS_DONE =
 #define ORT_FENCE() __threadfence()
 #define ORT_FFS64(m) __ffsll((unsigned long long)(m))
 #define ORT_LANE() ((int)__lane_id())
-/* lane-utilisation probe: event k happened in this wave with popc(pred) lanes taking part */
+/* lane-utilisation probe: event k happened in this wave with popc(pred) lanes taking part.  Diagnostics build only
+   (COUNTERS, ORT_DEBUG_UTIL=1); the waves of the first 32 workgroups record, into LDS (global atomics here would
+   keep every following load waiting behind them), flushed to memory when the workgroup ends */
 #define ORT_UTIL(sv, k, pred)                                                                        \
     do {                                                                                             \
-        if (COUNTERS && (sv).util) {                                                                 \
+        if (COUNTERS && (sv).util && blockIdx.x < 32u) {                                             \
             unsigned long long m_ = __ballot(pred);                                                  \
             if (m_ && (int)__lane_id() == __ffsll(m_) - 1) {                                         \
-                atomicAdd((sv).util + 2 * (k), 1ull);                                                \
-                atomicAdd((sv).util + 2 * (k) + 1, (unsigned long long)__popcll(m_));                \
+                atomicAdd(&g_lds_prof[2 * (k)], 1ull);                                               \
+                atomicAdd(&g_lds_prof[2 * (k) + 1], (unsigned long long)__popcll(m_));               \
             }                                                                                        \
+        }                                                                                            \
+    } while (0)
+/* phase timer (same diagnostics build): the shader cycles since the wave's previous mark are charged to phase k,
+   with the number of lanes for which pred holds */
+#define ORT_PHASE(pr, sv, k, pred)                                                                   \
+    do {                                                                                             \
+        if (COUNTERS && (pr).on) {                                                                   \
+            const unsigned long long now_ = __builtin_amdgcn_s_memtime();                            \
+            const unsigned long long m_ = __ballot(pred), a_ = __ballot(true);                       \
+            if ((int)__lane_id() == __ffsll(a_) - 1) {                                               \
+                atomicAdd(&g_lds_prof[32 + 3 * (k)], now_ - (pr).t);                                 \
+                atomicAdd(&g_lds_prof[32 + 3 * (k) + 1], 1ull);                                      \
+                atomicAdd(&g_lds_prof[32 + 3 * (k) + 2], (unsigned long long)__popcll(m_));          \
+            }                                                                                        \
+            (pr).t = __builtin_amdgcn_s_memtime();                                                   \
         }                                                                                            \
     } while (0)
 #endif
 
+#ifndef ORT_HOST_SIM
+__shared__ unsigned long long g_lds_prof[96]; /* diagnostics build only: [0,32) event probes, [32,96) phase timers */
+#endif
+
+struct Prof { unsigned long long t = 0; bool on = false; };
 
 #ifndef ORT_TRAV_WHILEWHILE
 #define ORT_TRAV_WHILEWHILE 1
@@ -511,7 +534,7 @@ ORT_D V3 focal_point(const RenderView &rv, uint32_t pxy, V3 cam_p, V3 cam_x, V3 
    is P.org / P.dir) or has run out of work (returns false).  On entry with P.ps == PS_HIT, h holds
    the resolved closest hit of the ray produced by the previous call. */
 template <bool COUNTERS, bool DIFFUSE = false>
-ORT_D bool produce_ray(const SceneView &sv, const RenderView &rv, PathState &P, const HitState &h, Counters &c,
+ORT_D bool produce_ray(const SceneView &sv, const RenderView &rv, PathState &P, const HitState &h, Counters &c, Prof &pr,
                        float *focal_cache = nullptr, int focal_stride = 0) {
     const V3 cam_p = mk(sv.cam[0], sv.cam[1], sv.cam[2]);
     const V3 cam_x = mk(sv.cam[3], sv.cam[4], sv.cam[5]);
@@ -522,6 +545,7 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderView &rv, PathState &P, 
 
     while (P.ps != PS_DONE) {
         ORT_UTIL(sv, 5, true);
+        ORT_PHASE(pr, sv, 8, true);
         bool bounce = false;
         float angle = 0.0f;
         BrdfDraw draw;
@@ -578,6 +602,7 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderView &rv, PathState &P, 
                 P.sample++;
                 P.ps = PS_SAMPLE;
             }
+            ORT_PHASE(pr, sv, 1, true);
         }
         if (!bounce) {
             /* a lane arrives here after its sample ended (PS_SAMPLE), or with nothing yet (PS_NEED_JOB).
@@ -654,6 +679,7 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderView &rv, PathState &P, 
             focal = focal_cache ? mk(focal_cache[0], focal_cache[focal_stride], focal_cache[2 * focal_stride])
                                 : focal_point(rv, P.pxy, cam_p, cam_x, cam_y, cam_z, focal_length);
             angle = rng_between(P.rng, 0.0f, 2 * kPi); /* ray.cpp:1232 */
+            ORT_PHASE(pr, sv, 2, true);
         }
         /* lanes that bounce and lanes that start a new camera sample both need cos/sin of one angle
            (lobe azimuth / aperture angle): the double-precision evaluation happens here once,
@@ -707,6 +733,7 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderView &rv, PathState &P, 
                 P.ps = PS_HIT;
             }
         }
+        ORT_PHASE(pr, sv, 3, true);
         return true;
     }
     return false;
@@ -714,13 +741,14 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderView &rv, PathState &P, 
 
 
 template <bool COUNTERS>
-ORT_D void begin_ray(const SceneView &sv, const PathState &P, Trav &T, HitState &h, Counters &c) {
+ORT_D void begin_ray(const SceneView &sv, const PathState &P, Trav &T, HitState &h, Counters &c, Prof &pr) {
     /* raycast_top_most_node (ray.cpp:1165-1176): start at the root */
     T.cur = 0;
     T.sp = 0;
     T.inv_d = mk(1.0f / P.dir.x, 1.0f / P.dir.y, 1.0f / P.dir.z); /* ray.cpp:210, once per ray */
     reset_hit(h, 3.402823466e+38f); /* Flt_Max, ray.cpp:627 */
     prologue_tests<COUNTERS>(sv, P.org, P.dir, T.inv_d, h, c);
+    ORT_PHASE(pr, sv, 4, true);
 }
 
 /* Closest hit: interruptible ordered DFS, replaces raycast_bvh (ray.cpp:624-822) on the fast tree.
@@ -738,13 +766,14 @@ constexpr float kCullSlack = 0.9997996f; /* <= 0.9999996 / 1.0002 */
 
 template <bool COUNTERS, int LDS_ENTRIES, int BLOCK>
 ORT_D bool traverse(const SceneView &sv, V3 org, V3 dir, Trav &T, HitState &h, uint32_t *lds_stack, uint32_t *spill, int tid,
-                    int refill_below, int descend_below, Counters &c, uint32_t excl = kNoPrim) {
+                    int refill_below, int descend_below, Counters &c, Prof &pr, uint32_t excl = kNoPrim) {
     bool tracing = true;
     uint32_t cur = T.cur;
     int sp = T.sp;
     const V3 inv_d = T.inv_d;
     while (tracing) {
         ORT_UTIL(sv, 2, true);
+        ORT_PHASE(pr, sv, 9, true);
         /* the straggler threshold of this round: descend_below, but never more than a quarter of the lanes
            that start descending now (a wave that enters with 20 such lanes should not stop at 8) */
         const int entering = ORT_POPC64(ORT_BALLOT((cur & LEAF_BIT) == 0u));
@@ -799,6 +828,7 @@ ORT_D bool traverse(const SceneView &sv, V3 org, V3 dir, Trav &T, HitState &h, u
             if (ORT_POPC64(ORT_BALLOT(true)) < stragglers) break;
 #endif
         }
+        ORT_PHASE(pr, sv, 5, true);
 #if ORT_TRAV_WHILEWHILE
         if (!(cur & LEAF_BIT)) {
             /* still on an interior node after the early exit above: nothing to do this round */
@@ -822,6 +852,7 @@ ORT_D bool traverse(const SceneView &sv, V3 org, V3 dir, Trav &T, HitState &h, u
                 if (sp < LDS_ENTRIES) cur = lds_stack[sp * BLOCK + tid];
                 else cur = ((volatile uint32_t *)spill)[sp - LDS_ENTRIES];
             }
+            ORT_PHASE(pr, sv, 6, true);
         }
         /* when most of the wave has finished its ray, let the finished lanes shade and refill */
         if (refill_below > 0 && ORT_POPC64(ORT_BALLOT(tracing)) < refill_below) break;
@@ -847,7 +878,7 @@ ORT_D bool traverse(const SceneView &sv, V3 org, V3 dir, Trav &T, HitState &h, u
    reference's scenes, 1e-2 with slanted cylinders) while the rest of the wave waits: the shape to ignore is
    a local of this rare branch, not a register carried through every ray's traversal. */
 template <bool COUNTERS, int LDS_ENTRIES, int BLOCK>
-ORT_D void resolve_hit(const SceneView &sv, V3 org, V3 dir, V3 inv_d, uint32_t lane_id, HitState &h, Counters &c, uint32_t *lds_stack,
+ORT_D void resolve_hit(const SceneView &sv, V3 org, V3 dir, V3 inv_d, uint32_t lane_id, HitState &h, Counters &c, Prof &pr, uint32_t *lds_stack,
                        uint32_t *spill, int tid) {
     bool recast = sv.force_fallback_mask != 0xffffffffu && (om_f32_bits(dir.x) & sv.force_fallback_mask) == 0u;
     if (!recast) {
@@ -869,7 +900,7 @@ ORT_D void resolve_hit(const SceneView &sv, V3 org, V3 dir, V3 inv_d, uint32_t l
                 /* CH_UNKNOWN: only hits at or before the leaf box's entry matter (the hit tests' "<" must accept t == gap) */
                 reset_hit(h, verdict == CH_REJECT ? 3.402823466e+38f : om_bits_f32(om_f32_bits(gap) + 1u));
                 prologue_tests<COUNTERS>(sv, org, dir, inv_d, h, c, w_prim);
-                (void)traverse<COUNTERS, LDS_ENTRIES - 4, BLOCK>(sv, org, dir, t2, h, lds_stack, spill, tid, 0, 0, c, w_prim);
+                (void)traverse<COUNTERS, LDS_ENTRIES - 4, BLOCK>(sv, org, dir, t2, h, lds_stack, spill, tid, 0, 0, c, pr, w_prim);
                 if (verdict == CH_UNKNOWN) {
                     if (h.hit_prim != kNoPrim || h.phantom_t <= gap) {
                         recast = true; /* something is there: order decides */
@@ -903,8 +934,14 @@ ORT_D void flush_counters(const RenderView &rv, const Counters &c, bool all) {
 
 /* persistent mode: one lane runs jobs until the job space is empty */
 template <bool COUNTERS, bool DIFFUSE = false>
-ORT_D void pt_lane(const SceneView &sv, const RenderView &rv, uint32_t *lds_stack, float *lds_focal, const int tid, const uint32_t lane_id) {
+ORT_D void pt_lane(const SceneView &sv, const RenderView &rv, uint32_t *lds_stack, float *lds_focal, const int tid, const uint32_t lane_id,
+                   bool prof_on = false) {
     uint32_t spill[kSpillStack];
+    Prof pr;
+    pr.on = prof_on;
+#ifndef ORT_HOST_SIM
+    if (COUNTERS && prof_on) pr.t = __builtin_amdgcn_s_memtime();
+#endif
     PathState P;
     HitState h;
     Trav T;
@@ -914,15 +951,17 @@ ORT_D void pt_lane(const SceneView &sv, const RenderView &rv, uint32_t *lds_stac
         if (!tracing) {
             ORT_UTIL(sv, 3, true);
             ORT_UTIL(sv, 4, P.ps == PS_HIT);
-            if (P.ps == PS_HIT) resolve_hit<COUNTERS, kLdsStack, kBlock>(sv, P.org, P.dir, T.inv_d, lane_id, h, c, lds_stack, spill, tid);
-            tracing = produce_ray<COUNTERS, DIFFUSE>(sv, rv, P, h, c, lds_focal + tid, kBlock);
+            ORT_PHASE(pr, sv, 7, true);
+            if (P.ps == PS_HIT) resolve_hit<COUNTERS, kLdsStack, kBlock>(sv, P.org, P.dir, T.inv_d, lane_id, h, c, pr, lds_stack, spill, tid);
+            ORT_PHASE(pr, sv, 0, P.ps == PS_HIT);
+            tracing = produce_ray<COUNTERS, DIFFUSE>(sv, rv, P, h, c, pr, lds_focal + tid, kBlock);
             if (tracing) {
-                begin_ray<COUNTERS>(sv, P, T, h, c);
+                begin_ray<COUNTERS>(sv, P, T, h, c, pr);
                 if (COUNTERS) c.rays++;
             }
         }
         if (ORT_BALLOT(P.ps != PS_DONE) == 0ull) break;
-        if (tracing) tracing = traverse<COUNTERS, kLdsStack, kBlock>(sv, P.org, P.dir, T, h, lds_stack, spill, tid, rv.refill_below, rv.descend_below, c);
+        if (tracing) tracing = traverse<COUNTERS, kLdsStack, kBlock>(sv, P.org, P.dir, T, h, lds_stack, spill, tid, rv.refill_below, rv.descend_below, c, pr);
     }
     flush_counters(rv, c, COUNTERS);
 }
@@ -953,7 +992,8 @@ ORT_D bool wf_shade_slot(const SceneView &sv, const RenderView &rv, const WfView
         P.primary = (fl & WF_PRIMARY) != 0;
         h.best_t = hh.x; h.hit_n = mk(hh.y, hh.z, hh.w); h.hit_prim = wf.hitp[i];
     }
-    bool tracing = produce_ray<COUNTERS>(sv, rv, P, h, c);
+    Prof pr;
+    bool tracing = produce_ray<COUNTERS>(sv, rv, P, h, c, pr);
     if (tracing) {
         wf.od0[i] = make_float4(P.org.x, P.org.y, P.org.z, P.dir.x);
         wf.od1[i] = make_float2(P.dir.y, P.dir.z);
@@ -978,9 +1018,10 @@ ORT_D void wf_trace_slot(const SceneView &sv, const WfView &wf, uint32_t i, uint
     P.org = mk(a.x, a.y, a.z); P.dir = mk(a.w, b.x, b.y);
     HitState h;
     Trav T;
-    begin_ray<COUNTERS>(sv, P, T, h, c);
-    traverse<COUNTERS, kWfLdsStack, kBlock>(sv, P.org, P.dir, T, h, lds_stack, spill, tid, 0, 0, c);
-    resolve_hit<COUNTERS, kWfLdsStack, kBlock>(sv, P.org, P.dir, T.inv_d, lane_id, h, c, lds_stack, spill, tid);
+    Prof pr;
+    begin_ray<COUNTERS>(sv, P, T, h, c, pr);
+    traverse<COUNTERS, kWfLdsStack, kBlock>(sv, P.org, P.dir, T, h, lds_stack, spill, tid, 0, 0, c, pr);
+    resolve_hit<COUNTERS, kWfLdsStack, kBlock>(sv, P.org, P.dir, T.inv_d, lane_id, h, c, pr, lds_stack, spill, tid);
     wf.hit0[i] = make_float4(h.best_t, h.hit_n.x, h.hit_n.y, h.hit_n.z);
     wf.hitp[i] = h.hit_prim;
 }
@@ -1016,7 +1057,16 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(ORT
 pt_persistent(SceneView sv, RenderView rv) {
     __shared__ uint32_t lds_stack[kLdsStack * kBlock];
     __shared__ float lds_focal[3 * kBlock]; /* focal[component][lane] */
-    pt_lane<COUNTERS, DIFFUSE>(sv, rv, lds_stack, lds_focal, (int)threadIdx.x, blockIdx.x * (uint32_t)kBlock + threadIdx.x);
+    const bool prof = COUNTERS && sv.util != nullptr && blockIdx.x < 32u;
+    if (prof) {
+        if (threadIdx.x < 96) g_lds_prof[threadIdx.x] = 0ull;
+        __syncthreads();
+    }
+    pt_lane<COUNTERS, DIFFUSE>(sv, rv, lds_stack, lds_focal, (int)threadIdx.x, blockIdx.x * (uint32_t)kBlock + threadIdx.x, prof);
+    if (prof) {
+        __syncthreads();
+        if (threadIdx.x < 96 && g_lds_prof[threadIdx.x]) atomicAdd(sv.util + threadIdx.x, g_lds_prof[threadIdx.x]);
+    }
 }
 
 /* wavefront kernels: fixed-size grids, grid-stride over the slots */
@@ -1217,8 +1267,8 @@ int device_upload(Scene *scene, int device, std::string *err) {
     if ((rc = upload_vec(rt.sphere_order, &d->sphere_order, err))) return rc;
     if ((rc = upload_vec(rt.box_order, &d->box_order, err))) return rc;
     if ((rc = upload_vec(rt.cyl_order, &d->cyl_order, err))) return rc;
-    ORT_HIP(hipMalloc((void **)&d->ctrl, 32 * sizeof(unsigned long long)));
-    ORT_HIP(hipMemset(d->ctrl, 0, 32 * sizeof(unsigned long long)));
+    ORT_HIP(hipMalloc((void **)&d->ctrl, 128 * sizeof(unsigned long long)));
+    ORT_HIP(hipMemset(d->ctrl, 0, 128 * sizeof(unsigned long long)));
     ORT_HIP(hipEventCreate(&d->ev0));
     ORT_HIP(hipEventCreate(&d->ev1));
     hipDeviceProp_t prop;
@@ -1431,7 +1481,7 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
     }
 
     const bool counters = (p->flags & ORT_RENDER_COUNTERS) != 0;
-    ORT_HIP(hipMemsetAsync(d->ctrl, 0, 32 * sizeof(unsigned long long), stream));
+    ORT_HIP(hipMemsetAsync(d->ctrl, 0, 128 * sizeof(unsigned long long), stream));
     /* persistent grid: 4 blocks of 256 lanes per CU, never more lanes than jobs */
     unsigned long long lanes_wanted = rv.job_count;
     unsigned int max_blocks = d->max_blocks;
@@ -1447,7 +1497,8 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
     } else {
         const char *kenv = getenv("ORT_KERNEL"); /* "general" forces the all-lobes kernel (A/B runs; same results) */
         const bool diffuse = d->diffuse_only && !(kenv && strcmp(kenv, "general") == 0);
-        if (counters) hipLaunchKernelGGL((pt_persistent<true, false>), dim3(grid), dim3(kBlock), 0, stream, sv, rv);
+        if (counters && diffuse && want_util) hipLaunchKernelGGL((pt_persistent<true, true>), dim3(grid), dim3(kBlock), 0, stream, sv, rv);
+        else if (counters) hipLaunchKernelGGL((pt_persistent<true, false>), dim3(grid), dim3(kBlock), 0, stream, sv, rv);
         else if (diffuse) hipLaunchKernelGGL((pt_persistent<false, true>), dim3(grid), dim3(kBlock), 0, stream, sv, rv);
         else hipLaunchKernelGGL((pt_persistent<false, false>), dim3(grid), dim3(kBlock), 0, stream, sv, rv);
         ORT_HIP(hipGetLastError());
@@ -1488,6 +1539,17 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
                 for (int k = 0; k < 8; ++k)
                     fprintf(stderr, "util %-40s wave-events %14llu  mean active lanes %6.2f\n", names[k], u[2 * k],
                             u[2 * k] ? (double)u[2 * k + 1] / (double)u[2 * k] : 0.0);
+                static const char *pnames[10] = {"resolve_hit (chain check)", "hit processing + bounce draw", "pixel / job / new sample", "sin/cos + normalise + ray setup",
+                                                "1/d + analytic prologue", "descend loop", "leaf", "pt_lane loop top (after traverse)",
+                                                "produce_ray entry (after resolve)", "traverse loop top"};
+                unsigned long long ph[30];
+                ORT_HIP(hipMemcpy(ph, d->ctrl + 8 + 32, sizeof(ph), hipMemcpyDeviceToHost));
+                double total = 0;
+                for (int k = 0; k < 10; ++k) total += (double)ph[3 * k];
+                for (int k = 0; k < 10; ++k)
+                    fprintf(stderr, "phase %-36s share %5.1f %%  cycles/mark %8.1f  marks %12llu  lanes at mark %5.1f\n", pnames[k],
+                            total > 0 ? 100.0 * (double)ph[3 * k] / total : 0.0, ph[3 * k + 1] ? (double)ph[3 * k] / (double)ph[3 * k + 1] : 0.0,
+                            ph[3 * k + 1], ph[3 * k + 1] ? (double)ph[3 * k + 2] / (double)ph[3 * k + 1] : 0.0);
             }
         }
     }

@@ -15,6 +15,8 @@
  * would not have seen it ("Exactness").
  */
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <float.h>
@@ -292,6 +294,26 @@ int build_ref_tree(Scene *scene, std::string *err) {
             if (d.first_child >= 0)
                 for (uint32_t k = 0; k < 8; ++k) queue.push_back((uint32_t)d.first_child + k);
         }
+    }
+    if (getenv("ORT_DEBUG_CHAINS")) { /* developer knob: the visibility chains of the analytic shapes */
+        auto dump = [&](const char *kind, const std::vector<uint32_t> &words, const std::vector<F4> *shape_boxes) {
+            for (size_t i = 0; i < words.size(); ++i) {
+                uint32_t len = words[i] >> 28, first = words[i] & 0x07ffffffu;
+                fprintf(stderr, "chain %s %zu len %u nested %u:", kind, i, len, (words[i] >> 27) & 1u);
+                for (uint32_t k = 0; k < len; ++k) {
+                    const F4 &lo = out->chain_boxes[2u * (first + k)], &hi = out->chain_boxes[2u * (first + k) + 1u];
+                    fprintf(stderr, " [%g %g %g | %g %g %g]", lo.x, lo.y, lo.z, hi.x, hi.y, hi.z);
+                }
+                if (shape_boxes) {
+                    const F4 &lo = (*shape_boxes)[2 * i], &hi = (*shape_boxes)[2 * i + 1];
+                    fprintf(stderr, "  shape [%g %g %g | %g %g %g]", lo.x, lo.y, lo.z, hi.x, hi.y, hi.z);
+                }
+                fprintf(stderr, "\n");
+            }
+        };
+        dump("box", out->box_chain, nullptr);
+        dump("sphere", out->sphere_chain, nullptr);
+        dump("cyl", out->cyl_chain, nullptr);
     }
     out->built = true;
     return ORT_OK;
