@@ -109,6 +109,23 @@ ORT_HD inline float ort_cosf(float xf)
     return (float)v;
 }
 
+/* ort_sinf(x) and ort_cosf(x) of the same argument in one go: the reduction and each of the two kernels are
+   evaluated once and the quadrant only selects and negates (exact), so both results have the bits of the two
+   separate functions -- without their eight divergent branch bodies on a GPU wave. */
+ORT_HD inline void ort_sincosf(float xf, float *sn, float *cs)
+{
+    double x = (double)xf, r;
+    if (!(x > -1.0e9 && x < 1.0e9)) { *sn = xf - xf; *cs = (xf - xf) + 1.0f; return; }
+    const int n = om_rem_pio2(x, &r);
+    const double sk = om_sin_k(r), ck = om_cos_k(r);
+    double sv = (n & 1) ? ck : sk; /* n & 3: 0 sin_k, 1 cos_k, 2 -sin_k, 3 -cos_k */
+    double cv = (n & 1) ? sk : ck; /*        0 cos_k, 1 -sin_k, 2 -cos_k, 3 sin_k */
+    if (n & 2) sv = -sv;
+    if ((n + 1) & 2) cv = -cv;
+    *sn = (float)sv;
+    *cs = (float)cv;
+}
+
 /* atan(t) for |t| <= 0.4143: alternating Taylor series to t^35. */
 ORT_HD inline double om_atan_series(double t)
 {

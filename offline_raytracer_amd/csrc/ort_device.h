@@ -351,6 +351,34 @@ ORT_D float hit_aab(V3 lo, V3 hi, V3 o, V3 inv, V3 &n) {
     return ht;
 }
 
+/* hit_aab for a ray whose origin and 1/d are all finite: no product (lo - o) * (1/d) can then be a NaN, and
+   without NaNs the reference's "?:" minimum / maximum (types.h:50-51) pick the same values as the hardware's
+   min / max instructions (up to the sign of a zero, which no comparison below and no caller's threshold can
+   tell apart) -- one instruction each instead of compare + select, and three-operand forms for the two
+   reductions.  Same hit distance, same normal. */
+ORT_D float hit_aab_finite(V3 lo, V3 hi, V3 o, V3 inv, V3 &n) {
+    float ht = -1.0f;
+    V3 t0 = had(sub(lo, o), inv), t1 = had(sub(hi, o), inv);
+    V3 tmin = mk(__builtin_fminf(t0.x, t1.x), __builtin_fminf(t0.y, t1.y), __builtin_fminf(t0.z, t1.z));
+    V3 tmax = mk(__builtin_fmaxf(t0.x, t1.x), __builtin_fmaxf(t0.y, t1.y), __builtin_fmaxf(t0.z, t1.z));
+    float max_of_min = __builtin_fmaxf(__builtin_fmaxf(tmin.x, tmin.y), tmin.z);
+    float min_of_max = __builtin_fminf(__builtin_fminf(tmax.x, tmax.y), tmax.z);
+    if (min_of_max >= max_of_min) {
+        float sx = (t0.x > t1.x) ? 1.0f : -1.0f, sy = (t0.y > t1.y) ? 1.0f : -1.0f, sz = (t0.z > t1.z) ? 1.0f : -1.0f;
+        float best = tmin.x;
+        V3 bn = mk(sx, 0, 0);
+        if (best < tmin.y) { best = tmin.y; bn = mk(0, sy, 0); }
+        if (best < tmin.z) { best = tmin.z; bn = mk(0, 0, sz); }
+        ht = max_of_min; /* sic: may be negative; callers threshold */
+        n = bn;
+    }
+    return ht;
+}
+/* true when every component is finite (x - x is 0 for a finite x, NaN otherwise) */
+ORT_D bool all_finite6(V3 a, V3 b) {
+    return (((a.x - a.x) + (a.y - a.y) + (a.z - a.z)) + ((b.x - b.x) + (b.y - b.y) + (b.z - b.z))) == 0.0f;
+}
+
 /* the same, distance only (node admission tests of the reference octree) */
 ORT_D float hit_aab_t(V3 lo, V3 hi, V3 o, V3 inv) {
     V3 t0 = had(sub(lo, o), inv), t1 = had(sub(hi, o), inv);

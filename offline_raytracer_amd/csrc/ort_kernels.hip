@@ -35,7 +35,26 @@ constexpr int kSpillStack = 40;  /* scratch tail; ort_tree.cpp bounds the depth 
 constexpr uint32_t kBfsPoolQueues = 256;      /* queues of the breadth-first fallback, shared by all lanes */
 constexpr size_t kBfsPoolBytes = 512u << 20; /* at most; a queue holds one entry per reference-tree node */
 
+/* Small read-only tables every ray touches live in LDS, copied there once per workgroup: ~100 cycles of latency
+   instead of a trip to L1 / L2 on the critical path of every ray (the kernel is latency-bound: DESIGN.md).
+   Layout in float4 units; a table that does not fit its slot stays in HBM (SceneView::tab_flags). */
+constexpr int kTabRoot = 0;                      /* node 0 of the fast tree (4) */
+constexpr int kTabPro = 4;                       /* the analytic prologue's shapes: boxes (2 each), spheres (1), cylinders (4) */
+constexpr int kTabProCap = 40;
+constexpr int kTabLights = kTabPro + kTabProCap; /* light_is_sphere[64] as u32 */
+constexpr int kTabLightCap = 64;
+constexpr int kTabBoxMat = kTabLights + kTabLightCap / 4; /* material index of box / sphere / cylinder [100 each] as u32 */
+constexpr int kTabPrimMatCap = 100;
+constexpr int kTabSphereMat = kTabBoxMat + kTabPrimMatCap / 4;
+constexpr int kTabCylMat = kTabSphereMat + kTabPrimMatCap / 4;
+constexpr int kTabMats = kTabCylMat + kTabPrimMatCap / 4; /* DevMaterial records, 5 each */
+constexpr int kTabMatCap = 48;
+constexpr int kTabF4 = kTabMats + 5 * kTabMatCap; /* 375 float4 = 6000 B */
+enum : uint32_t { TAB_PRO = 1u, TAB_LIGHTS = 2u, TAB_PRIM_MATS = 4u, TAB_MATS = 8u };
+
 struct SceneView {
+    const float4 *tab_src;    /* kTabF4 float4, the image of the LDS tables */
+    uint32_t tab_flags;
     const float4 *nodes;      /* 4 per node */
     const float4 *tris;       /* 3 per triangle: v0 e1 e2 n (12 floats) */
     const uint32_t *tri_mat;
@@ -108,6 +127,8 @@ struct DeviceScene {
     void *nodes = nullptr, *tris = nullptr, *tri_mat = nullptr, *spheres = nullptr, *sphere_mat = nullptr;
     void *boxes = nullptr, *box_mat = nullptr, *cyls = nullptr, *cyl_mat = nullptr, *materials = nullptr;
     void *light_is_sphere = nullptr;
+    void *tab = nullptr; /* image of the LDS tables (kTabF4 float4) */
+    uint32_t tab_flags = 0;
     uint32_t light_count = 0;
     bool diffuse_only = false; /* no surface material can enter the specular / transmission blocks */
     void *ref_nodes = nullptr, *ref_recs = nullptr, *chain_boxes = nullptr;
@@ -201,6 +222,9 @@ __shared__ unsigned long long g_lds_prof[96]; /* diagnostics build only: [0,32) 
 
 struct Prof { unsigned long long t = 0; bool on = false; };
 
+#ifndef ORT_ROOT_PEEL
+#define ORT_ROOT_PEEL 0 /* 1: the root node is visited in begin_ray, converged, from the LDS tables (measured: -10 % on the bunny room, the visit no longer shares its instructions with the stragglers' node visits) */
+#endif
 #ifndef ORT_TRAV_WHILEWHILE
 #define ORT_TRAV_WHILEWHILE 1
 #endif
@@ -218,10 +242,10 @@ ORT_D uint32_t prim_order(const SceneView &sv, uint32_t kind, uint32_t slot) {
 
 /* one primitive against the ray, exactly as raycast_bvh does per record (ray.cpp:647-716):
    accept when hit_t >= 1e-6 and strictly closer than the best so far */
-template <bool COUNTERS, bool EXACT_ORDER>
+template <bool COUNTERS, bool EXACT_ORDER, bool FINITE_RAY = false, bool FROM_TAB = false>
 ORT_D void test_prim(const SceneView &sv, uint32_t kind, uint32_t slot, V3 org, V3 dir, V3 inv_d, float &best_t, V3 &hit_n,
                      uint32_t &hit_prim, float &phantom_t, float &runner_t, unsigned long long &c_tris, unsigned long long &c_analytic,
-                     uint32_t excl = 0xffffffffu) {
+                     uint32_t excl = 0xffffffffu, const float4 *rec = nullptr /* FROM_TAB: the shape's record in the LDS tables */) {
     float t;
     V3 n = mk(0, 0, 0);
     bool tangent = false;
@@ -233,16 +257,20 @@ ORT_D void test_prim(const SceneView &sv, uint32_t kind, uint32_t slot, V3 org, 
         t = hit_triangle(mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), mk(b.z, b.w, c.x), org, dir);
         n = mk(c.y, c.z, c.w);
     } else if (kind == PRIM_SPHERE) {
-        float4 s = sv.spheres[slot];
+        float4 s;
+        if (FROM_TAB) s = rec[0]; else s = sv.spheres[slot];
         if (COUNTERS) c_analytic++;
         t = hit_sphere(mk(s.x, s.y, s.z), s.w, org, dir, n, tangent);
     } else if (kind == PRIM_BOX) {
-        float4 lo = sv.boxes[2u * slot], hi = sv.boxes[2u * slot + 1u];
+        float4 lo, hi;
+        if (FROM_TAB) { lo = rec[0]; hi = rec[1]; } else { lo = sv.boxes[2u * slot]; hi = sv.boxes[2u * slot + 1u]; }
         if (COUNTERS) c_analytic++;
-        t = hit_aab(mk(lo.x, lo.y, lo.z), mk(hi.x, hi.y, hi.z), org, inv_d, n);
+        t = FINITE_RAY ? hit_aab_finite(mk(lo.x, lo.y, lo.z), mk(hi.x, hi.y, hi.z), org, inv_d, n)
+                       : hit_aab(mk(lo.x, lo.y, lo.z), mk(hi.x, hi.y, hi.z), org, inv_d, n);
     } else {
-        const float4 *cp = sv.cyls + 4u * slot;
-        float4 a = cp[0], b = cp[1], c = cp[2], d = cp[3];
+        float4 a, b, c, d;
+        if (FROM_TAB) { a = rec[0]; b = rec[1]; c = rec[2]; d = rec[3]; }
+        else { const float4 *cp = sv.cyls + 4u * slot; a = cp[0]; b = cp[1]; c = cp[2]; d = cp[3]; }
         if (COUNTERS) c_analytic++;
         t = hit_cylinder(mk(a.x, a.y, a.z), a.w, mk(b.x, b.y, b.z), mk(b.w, c.x, c.y), mk(c.z, c.w, d.x), d.y, org, dir, n);
     }
@@ -487,14 +515,23 @@ ORT_D void reset_hit(HitState &h, float best_t) {
 
 /* the analytic prologue (ort_tree.cpp): the lanes that start a ray now all test the same shape at the same
    time -- uniform addresses, no divergence -- and enter the tree with best_t already set */
-template <bool COUNTERS>
-ORT_D void prologue_tests(const SceneView &sv, V3 org, V3 dir, V3 inv_d, HitState &h, Counters &c, uint32_t excl = kNoPrim) {
-    for (uint32_t i = 0; i < sv.pro_boxes; ++i)
-        test_prim<COUNTERS, false>(sv, PRIM_BOX, i, org, dir, inv_d, h.best_t, h.hit_n, h.hit_prim, h.phantom_t, h.runner_t, c.tris, c.analytic, excl);
+template <bool COUNTERS, bool TABS>
+ORT_D void prologue_tests(const SceneView &sv, const float4 *tab, V3 org, V3 dir, V3 inv_d, HitState &h, Counters &c, uint32_t excl = kNoPrim) {
+    /* TABS: the shapes' records come from the LDS tables */
+    const float4 *pb = tab + kTabPro, *ps = pb + 2u * sv.pro_boxes, *pc = ps + sv.pro_spheres;
+    /* boxes: when every lane's origin and 1/d are finite (all but a handful of rays), the slab test runs on the
+       hardware's min / max (hit_aab_finite: same values); wave-uniform choice, so no lane waits for the other form */
+    if (ORT_BALLOT(!all_finite6(org, inv_d)) == 0ull) {
+        for (uint32_t i = 0; i < sv.pro_boxes; ++i)
+            test_prim<COUNTERS, false, true, TABS>(sv, PRIM_BOX, i, org, dir, inv_d, h.best_t, h.hit_n, h.hit_prim, h.phantom_t, h.runner_t, c.tris, c.analytic, excl, pb + 2u * i);
+    } else {
+        for (uint32_t i = 0; i < sv.pro_boxes; ++i)
+            test_prim<COUNTERS, false, false, TABS>(sv, PRIM_BOX, i, org, dir, inv_d, h.best_t, h.hit_n, h.hit_prim, h.phantom_t, h.runner_t, c.tris, c.analytic, excl, pb + 2u * i);
+    }
     for (uint32_t i = 0; i < sv.pro_spheres; ++i)
-        test_prim<COUNTERS, false>(sv, PRIM_SPHERE, i, org, dir, inv_d, h.best_t, h.hit_n, h.hit_prim, h.phantom_t, h.runner_t, c.tris, c.analytic, excl);
+        test_prim<COUNTERS, false, false, TABS>(sv, PRIM_SPHERE, i, org, dir, inv_d, h.best_t, h.hit_n, h.hit_prim, h.phantom_t, h.runner_t, c.tris, c.analytic, excl, ps + i);
     for (uint32_t i = 0; i < sv.pro_cyls; ++i)
-        test_prim<COUNTERS, false>(sv, PRIM_CYL, i, org, dir, inv_d, h.best_t, h.hit_n, h.hit_prim, h.phantom_t, h.runner_t, c.tris, c.analytic, excl);
+        test_prim<COUNTERS, false, false, TABS>(sv, PRIM_CYL, i, org, dir, inv_d, h.best_t, h.hit_n, h.hit_prim, h.phantom_t, h.runner_t, c.tris, c.analytic, excl, pc + 4u * i);
 }
 
 /* the exact answer: raycast_bvh emulated literally on the reference-compatible octree.  Rare.  The lanes of a
@@ -533,8 +570,8 @@ ORT_D V3 focal_point(const RenderView &rv, uint32_t pxy, V3 cam_p, V3 cam_x, V3 
 /* Advance the lane's path state machine until it has produced the next ray (returns true; the ray
    is P.org / P.dir) or has run out of work (returns false).  On entry with P.ps == PS_HIT, h holds
    the resolved closest hit of the ray produced by the previous call. */
-template <bool COUNTERS, bool DIFFUSE = false>
-ORT_D bool produce_ray(const SceneView &sv, const RenderView &rv, PathState &P, const HitState &h, Counters &c, Prof &pr,
+template <bool COUNTERS, bool DIFFUSE = false, bool TABS = false>
+ORT_D bool produce_ray(const SceneView &sv, const RenderView &rv, const float4 *tab, PathState &P, const HitState &h, Counters &c, Prof &pr,
                        float *focal_cache = nullptr, int focal_stride = 0) {
     const V3 cam_p = mk(sv.cam[0], sv.cam[1], sv.cam[2]);
     const V3 cam_x = mk(sv.cam[3], sv.cam[4], sv.cam[5]);
@@ -557,13 +594,22 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderView &rv, PathState &P, 
             uint32_t hit_mat = 0;
             if (h.hit_prim != kNoPrim) {
                 uint32_t hk = h.hit_prim >> 28, hs = h.hit_prim & 0x00ffffffu;
-                hit_mat = (hk == PRIM_TRI) ? sv.tri_mat[hs] : (hk == PRIM_SPHERE) ? sv.sphere_mat[hs]
-                        : (hk == PRIM_BOX) ? sv.box_mat[hs] : sv.cyl_mat[hs];
+                if (TABS) {
+                    const uint32_t *tm = (const uint32_t *)tab;
+                    hit_mat = (hk == PRIM_TRI) ? sv.tri_mat[hs] : (hk == PRIM_SPHERE) ? tm[4 * kTabSphereMat + hs]
+                            : (hk == PRIM_BOX) ? tm[4 * kTabBoxMat + hs] : tm[4 * kTabCylMat + hs];
+                } else {
+                    hit_mat = (hk == PRIM_TRI) ? sv.tri_mat[hs] : (hk == PRIM_SPHERE) ? sv.sphere_mat[hs]
+                            : (hk == PRIM_BOX) ? sv.box_mat[hs] : sv.cyl_mat[hs];
+                }
             }
             n = normalize(h.hit_n);
             ORT_SIM_RAY_HOOK((int)(P.pxy & 0xffffu), (int)(P.pxy >> 16), P.org, P.dir, h.best_t, n, hit_mat);
             if (COUNTERS && P.primary) c.paths++;
-            if (hit_mat) m = load_mat(sv.materials, hit_mat);
+            if (hit_mat) {
+                if (TABS) m = load_mat(tab + kTabMats, hit_mat);
+                else m = load_mat(sv.materials, hit_mat);
+            }
             if (!hit_mat) {
                 alive = false; /* bounce miss: ray.cpp:1418-1421; primary miss: undefined in the reference, defined: terminate */
             } else if (m.is_light) {
@@ -593,7 +639,10 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderView &rv, PathState &P, 
                 rng_step(P.rng);
                 if (sv.light_count) {
                     uint32_t li = P.rng % sv.light_count;
-                    if (sv.light_is_sphere[li]) { rng_step(P.rng); rng_step(P.rng); rng_step(P.rng); rng_step(P.rng); }
+                    uint32_t is_sphere;
+                    if (TABS) is_sphere = ((const uint32_t *)tab)[4 * kTabLights + li];
+                    else is_sphere = sv.light_is_sphere[li];
+                    if (is_sphere) { rng_step(P.rng); rng_step(P.rng); rng_step(P.rng); rng_step(P.rng); }
                 }
                 ORT_UTIL(sv, 6, true);
                 draw = sample_brdf_draw(P.rng, kRoughness, m);
@@ -685,7 +734,8 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderView &rv, PathState &P, 
            (lobe azimuth / aperture angle): the double-precision evaluation happens here once,
            converged, instead of once in each branch (same operand, same bits) */
         ORT_UTIL(sv, 7, true);
-        float cs = ort_cosf(angle), sn = ort_sinf(angle);
+        float cs, sn;
+        ort_sincosf(angle, &sn, &cs);
         if (DIFFUSE) { /* the leaner flavour has the registers for the wider merge; the all-lobes one spills on it */
             /* Bounce lanes normalise twice here (the surface normal again, ray.cpp:1069, and the sampled direction,
                :1158) and so do camera lanes (the ray direction, :1240, and -- sic -- the direction again for wo,
@@ -740,14 +790,70 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderView &rv, PathState &P, 
 }
 
 
-template <bool COUNTERS>
-ORT_D void begin_ray(const SceneView &sv, const PathState &P, Trav &T, HitState &h, Counters &c, Prof &pr) {
-    /* raycast_top_most_node (ray.cpp:1165-1176): start at the root */
+/* a child is skipped only when its entry distance (less the slab test's rounding margin, 0.9999996)
+   is beyond best_t * 1.0002: every primitive hit within 2e-4 of the final winner is therefore tested,
+   which is what makes HitState::runner_t exact in that window */
+constexpr float kCullSlack = 0.9997996f; /* <= 0.9999996 / 1.0002 */
+
+/* One interior node of the fast tree (record a b cc d) against the ray: both child boxes in the reference's own
+   (p - o) * (1/d) form (ray.cpp:215-222) with ulp margins, conservative; fminf/fmaxf drop the NaN of 0 * inf, i.e. that
+   axis is ignored.  Continues with the nearer child, stacks the farther one, or pops. */
+template <bool COUNTERS, int LDS_ENTRIES, int BLOCK>
+ORT_D void visit_node(float4 a, float4 b, float4 cc, float4 d, V3 org, V3 inv_d, float best_t, uint32_t &cur, int &sp, uint32_t *lds_stack,
+                      uint32_t *spill, int tid, Counters &c) {
+    uint32_t c0 = om_f32_bits(d.x), c1 = om_f32_bits(d.y);
+    if (COUNTERS) c.nodes += 2;
+    /* child 0: lo = a.xyz, hi = (a.w, b.x, b.y); child 1: lo = (b.z, b.w, cc.x), hi = cc.yzw */
+    float t0x = (a.x - org.x) * inv_d.x, t1x = (a.w - org.x) * inv_d.x;
+    float t0y = (a.y - org.y) * inv_d.y, t1y = (b.x - org.y) * inv_d.y;
+    float t0z = (a.z - org.z) * inv_d.z, t1z = (b.y - org.z) * inv_d.z;
+    float n0 = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
+    float f0 = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
+    float u0x = (b.z - org.x) * inv_d.x, u1x = (cc.y - org.x) * inv_d.x;
+    float u0y = (b.w - org.y) * inv_d.y, u1y = (cc.z - org.y) * inv_d.y;
+    float u0z = (cc.x - org.z) * inv_d.z, u1z = (cc.w - org.z) * inv_d.z;
+    float n1 = fmaxf(fmaxf(fminf(u0x, u1x), fminf(u0y, u1y)), fminf(u0z, u1z));
+    float f1 = fminf(fminf(fmaxf(u0x, u1x), fmaxf(u0y, u1y)), fmaxf(u0z, u1z));
+    /* children with a sphere below are not culled by distance (phantom tangent hits) */
+    bool h0 = (f0 * 1.0000004f >= n0) && (f0 >= 0.0f) && ((n0 * kCullSlack < best_t) || (c0 & SPHERE_BELOW_BIT));
+    bool h1 = (f1 * 1.0000004f >= n1) && (f1 >= 0.0f) && ((n1 * kCullSlack < best_t) || (c1 & SPHERE_BELOW_BIT)) && (c1 != EMPTY_CHILD);
+    if (h0 && h1) {
+        bool swap = n1 < n0;
+        uint32_t farc = swap ? c0 : c1;
+        cur = swap ? c1 : c0;
+        if (sp < LDS_ENTRIES) lds_stack[sp * BLOCK + tid] = farc;
+        else spill[sp - LDS_ENTRIES] = farc;
+        sp++;
+    } else if (h0) {
+        cur = c0;
+    } else if (h1) {
+        cur = c1;
+    } else if (sp == 0) {
+        cur = kTraversalDone;
+    } else {
+        sp--;
+        /* two real loads behind a branch (the volatile keeps the compiler from merging them into one
+           flat_load of a selected generic pointer): the LDS side becomes a plain ds_read */
+        if (sp < LDS_ENTRIES) cur = lds_stack[sp * BLOCK + tid];
+        else cur = ((volatile uint32_t *)spill)[sp - LDS_ENTRIES];
+    }
+}
+
+/* raycast_top_most_node (ray.cpp:1165-1176): start at the root.  The lanes that start a ray now are converged: they
+   test the analytic prologue together and visit the root node together, its record read from the LDS tables, before
+   they join the traversal loop (whose other lanes are at arbitrary depths) */
+template <bool COUNTERS, bool TABS, int LDS_ENTRIES, int BLOCK>
+ORT_D void begin_ray(const SceneView &sv, const float4 *tab, const PathState &P, Trav &T, HitState &h, Counters &c, Prof &pr,
+                     uint32_t *lds_stack, uint32_t *spill, int tid) {
     T.cur = 0;
     T.sp = 0;
     T.inv_d = mk(1.0f / P.dir.x, 1.0f / P.dir.y, 1.0f / P.dir.z); /* ray.cpp:210, once per ray */
     reset_hit(h, 3.402823466e+38f); /* Flt_Max, ray.cpp:627 */
-    prologue_tests<COUNTERS>(sv, P.org, P.dir, T.inv_d, h, c);
+    prologue_tests<COUNTERS, TABS>(sv, tab, P.org, P.dir, T.inv_d, h, c);
+    if (TABS && ORT_ROOT_PEEL) {
+        const float4 *np = tab + kTabRoot;
+        visit_node<COUNTERS, LDS_ENTRIES, BLOCK>(np[0], np[1], np[2], np[3], P.org, T.inv_d, h.best_t, T.cur, T.sp, lds_stack, spill, tid, c);
+    }
     ORT_PHASE(pr, sv, 4, true);
 }
 
@@ -759,11 +865,6 @@ ORT_D void begin_ray(const SceneView &sv, const PathState &P, Trav &T, HitState 
  * conservative; fminf/fmaxf drop the NaN of 0 * inf, i.e. that axis is ignored.
  * Returns when this lane's ray is finished, or -- refill_below > 0 -- as soon as fewer than
  * refill_below lanes of the wave are still traversing (the caller resumes later: all state is in T/h). */
-/* a child is skipped only when its entry distance (less the slab test's rounding margin, 0.9999996)
-   is beyond best_t * 1.0002: every primitive hit within 2e-4 of the final winner is therefore tested,
-   which is what makes HitState::runner_t exact in that window */
-constexpr float kCullSlack = 0.9997996f; /* <= 0.9999996 / 1.0002 */
-
 template <bool COUNTERS, int LDS_ENTRIES, int BLOCK>
 ORT_D bool traverse(const SceneView &sv, V3 org, V3 dir, Trav &T, HitState &h, uint32_t *lds_stack, uint32_t *spill, int tid,
                     int refill_below, int descend_below, Counters &c, Prof &pr, uint32_t excl = kNoPrim) {
@@ -785,43 +886,7 @@ ORT_D bool traverse(const SceneView &sv, V3 org, V3 dir, Trav &T, HitState &h, u
 #endif
             ORT_UTIL(sv, 0, true);
             const float4 *np = sv.nodes + 4u * (cur & NODE_INDEX_MASK);
-            float4 a = np[0], b = np[1], cc = np[2], d = np[3];
-            uint32_t c0 = om_f32_bits(d.x), c1 = om_f32_bits(d.y);
-            if (COUNTERS) c.nodes += 2;
-            /* child 0: lo = a.xyz, hi = (a.w, b.x, b.y); child 1: lo = (b.z, b.w, cc.x), hi = cc.yzw */
-            float t0x = (a.x - org.x) * inv_d.x, t1x = (a.w - org.x) * inv_d.x;
-            float t0y = (a.y - org.y) * inv_d.y, t1y = (b.x - org.y) * inv_d.y;
-            float t0z = (a.z - org.z) * inv_d.z, t1z = (b.y - org.z) * inv_d.z;
-            float n0 = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));
-            float f0 = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));
-            float u0x = (b.z - org.x) * inv_d.x, u1x = (cc.y - org.x) * inv_d.x;
-            float u0y = (b.w - org.y) * inv_d.y, u1y = (cc.z - org.y) * inv_d.y;
-            float u0z = (cc.x - org.z) * inv_d.z, u1z = (cc.w - org.z) * inv_d.z;
-            float n1 = fmaxf(fmaxf(fminf(u0x, u1x), fminf(u0y, u1y)), fminf(u0z, u1z));
-            float f1 = fminf(fminf(fmaxf(u0x, u1x), fmaxf(u0y, u1y)), fmaxf(u0z, u1z));
-            /* children with a sphere below are not culled by distance (phantom tangent hits) */
-            bool h0 = (f0 * 1.0000004f >= n0) && (f0 >= 0.0f) && ((n0 * kCullSlack < h.best_t) || (c0 & SPHERE_BELOW_BIT));
-            bool h1 = (f1 * 1.0000004f >= n1) && (f1 >= 0.0f) && ((n1 * kCullSlack < h.best_t) || (c1 & SPHERE_BELOW_BIT)) && (c1 != EMPTY_CHILD);
-            if (h0 && h1) {
-                bool swap = n1 < n0;
-                uint32_t farc = swap ? c0 : c1;
-                cur = swap ? c1 : c0;
-                if (sp < LDS_ENTRIES) lds_stack[sp * BLOCK + tid] = farc;
-                else spill[sp - LDS_ENTRIES] = farc;
-                sp++;
-            } else if (h0) {
-                cur = c0;
-            } else if (h1) {
-                cur = c1;
-            } else if (sp == 0) {
-                cur = kTraversalDone;
-            } else {
-                sp--;
-                /* two real loads behind a branch (the volatile keeps the compiler from merging them into one
-                   flat_load of a selected generic pointer): the LDS side becomes a plain ds_read */
-                if (sp < LDS_ENTRIES) cur = lds_stack[sp * BLOCK + tid];
-                else cur = ((volatile uint32_t *)spill)[sp - LDS_ENTRIES];
-            }
+            visit_node<COUNTERS, LDS_ENTRIES, BLOCK>(np[0], np[1], np[2], np[3], org, inv_d, h.best_t, cur, sp, lds_stack, spill, tid, c);
 #if ORT_TRAV_WHILEWHILE
             /* the stragglers of the descend loop would keep the rest of the wave waiting: break out
                and come back for them (their cur / sp carry over) */
@@ -877,9 +942,9 @@ ORT_D bool traverse(const SceneView &sv, V3 org, V3 dir, Trav &T, HitState &h, u
    The extra traversals run here, to completion, for the lanes that need them (1e-5 of the rays of the
    reference's scenes, 1e-2 with slanted cylinders) while the rest of the wave waits: the shape to ignore is
    a local of this rare branch, not a register carried through every ray's traversal. */
-template <bool COUNTERS, int LDS_ENTRIES, int BLOCK>
-ORT_D void resolve_hit(const SceneView &sv, V3 org, V3 dir, V3 inv_d, uint32_t lane_id, HitState &h, Counters &c, Prof &pr, uint32_t *lds_stack,
-                       uint32_t *spill, int tid) {
+template <bool COUNTERS, bool TABS, int LDS_ENTRIES, int BLOCK>
+ORT_D void resolve_hit(const SceneView &sv, const float4 *tab, V3 org, V3 dir, V3 inv_d, uint32_t lane_id, HitState &h, Counters &c, Prof &pr,
+                       uint32_t *lds_stack, uint32_t *spill, int tid) {
     bool recast = sv.force_fallback_mask != 0xffffffffu && (om_f32_bits(dir.x) & sv.force_fallback_mask) == 0u;
     if (!recast) {
         if (h.phantom_t <= h.best_t) {
@@ -899,7 +964,7 @@ ORT_D void resolve_hit(const SceneView &sv, V3 org, V3 dir, V3 inv_d, uint32_t l
                 t2.cur = 0; t2.sp = 0; t2.inv_d = inv_d;
                 /* CH_UNKNOWN: only hits at or before the leaf box's entry matter (the hit tests' "<" must accept t == gap) */
                 reset_hit(h, verdict == CH_REJECT ? 3.402823466e+38f : om_bits_f32(om_f32_bits(gap) + 1u));
-                prologue_tests<COUNTERS>(sv, org, dir, inv_d, h, c, w_prim);
+                prologue_tests<COUNTERS, TABS>(sv, tab, org, dir, inv_d, h, c, w_prim);
                 (void)traverse<COUNTERS, LDS_ENTRIES - 4, BLOCK>(sv, org, dir, t2, h, lds_stack, spill, tid, 0, 0, c, pr, w_prim);
                 if (verdict == CH_UNKNOWN) {
                     if (h.hit_prim != kNoPrim || h.phantom_t <= gap) {
@@ -933,9 +998,9 @@ ORT_D void flush_counters(const RenderView &rv, const Counters &c, bool all) {
 }
 
 /* persistent mode: one lane runs jobs until the job space is empty */
-template <bool COUNTERS, bool DIFFUSE = false>
-ORT_D void pt_lane(const SceneView &sv, const RenderView &rv, uint32_t *lds_stack, float *lds_focal, const int tid, const uint32_t lane_id,
-                   bool prof_on = false) {
+template <bool COUNTERS, bool DIFFUSE = false, bool TABS = false>
+ORT_D void pt_lane(const SceneView &sv, const RenderView &rv, const float4 *tab, uint32_t *lds_stack, float *lds_focal, const int tid,
+                   const uint32_t lane_id, bool prof_on = false) {
     uint32_t spill[kSpillStack];
     Prof pr;
     pr.on = prof_on;
@@ -952,11 +1017,11 @@ ORT_D void pt_lane(const SceneView &sv, const RenderView &rv, uint32_t *lds_stac
             ORT_UTIL(sv, 3, true);
             ORT_UTIL(sv, 4, P.ps == PS_HIT);
             ORT_PHASE(pr, sv, 7, true);
-            if (P.ps == PS_HIT) resolve_hit<COUNTERS, kLdsStack, kBlock>(sv, P.org, P.dir, T.inv_d, lane_id, h, c, pr, lds_stack, spill, tid);
+            if (P.ps == PS_HIT) resolve_hit<COUNTERS, TABS, kLdsStack, kBlock>(sv, tab, P.org, P.dir, T.inv_d, lane_id, h, c, pr, lds_stack, spill, tid);
             ORT_PHASE(pr, sv, 0, P.ps == PS_HIT);
-            tracing = produce_ray<COUNTERS, DIFFUSE>(sv, rv, P, h, c, pr, lds_focal + tid, kBlock);
+            tracing = produce_ray<COUNTERS, DIFFUSE, TABS>(sv, rv, tab, P, h, c, pr, lds_focal + tid, kBlock);
             if (tracing) {
-                begin_ray<COUNTERS>(sv, P, T, h, c, pr);
+                begin_ray<COUNTERS, TABS, kLdsStack, kBlock>(sv, tab, P, T, h, c, pr, lds_stack, spill, tid);
                 if (COUNTERS) c.rays++;
             }
         }
@@ -973,7 +1038,7 @@ constexpr int kWfSpill = 48;
 
 /* one slot: resume its path, produce the next ray, store everything back; returns true if a ray was produced */
 template <bool COUNTERS>
-ORT_D bool wf_shade_slot(const SceneView &sv, const RenderView &rv, const WfView &wf, uint32_t i, Counters &c) {
+ORT_D bool wf_shade_slot(const SceneView &sv, const RenderView &rv, const float4 *tab, const WfView &wf, uint32_t i, Counters &c) {
     uint32_t fl = wf.flags[i];
     PathState P;
     P.ps = (int)(fl & 7u);
@@ -993,7 +1058,7 @@ ORT_D bool wf_shade_slot(const SceneView &sv, const RenderView &rv, const WfView
         h.best_t = hh.x; h.hit_n = mk(hh.y, hh.z, hh.w); h.hit_prim = wf.hitp[i];
     }
     Prof pr;
-    bool tracing = produce_ray<COUNTERS>(sv, rv, P, h, c, pr);
+    bool tracing = produce_ray<COUNTERS>(sv, rv, tab, P, h, c, pr);
     if (tracing) {
         wf.od0[i] = make_float4(P.org.x, P.org.y, P.org.z, P.dir.x);
         wf.od1[i] = make_float2(P.dir.y, P.dir.z);
@@ -1009,8 +1074,8 @@ ORT_D bool wf_shade_slot(const SceneView &sv, const RenderView &rv, const WfView
 
 /* one slot: closest hit of its ray, resolved to the reference's answer */
 template <bool COUNTERS>
-ORT_D void wf_trace_slot(const SceneView &sv, const WfView &wf, uint32_t i, uint32_t lane_id, uint32_t *lds_stack, uint32_t *spill,
-                         int tid, Counters &c) {
+ORT_D void wf_trace_slot(const SceneView &sv, const float4 *tab, const WfView &wf, uint32_t i, uint32_t lane_id, uint32_t *lds_stack,
+                         uint32_t *spill, int tid, Counters &c) {
     if (!(wf.flags[i] & WF_HAS_RAY)) return;
     float4 a = wf.od0[i];
     float2 b = wf.od1[i];
@@ -1019,9 +1084,9 @@ ORT_D void wf_trace_slot(const SceneView &sv, const WfView &wf, uint32_t i, uint
     HitState h;
     Trav T;
     Prof pr;
-    begin_ray<COUNTERS>(sv, P, T, h, c, pr);
+    begin_ray<COUNTERS, false, kWfLdsStack, kBlock>(sv, tab, P, T, h, c, pr, lds_stack, spill, tid);
     traverse<COUNTERS, kWfLdsStack, kBlock>(sv, P.org, P.dir, T, h, lds_stack, spill, tid, 0, 0, c, pr);
-    resolve_hit<COUNTERS, kWfLdsStack, kBlock>(sv, P.org, P.dir, T.inv_d, lane_id, h, c, pr, lds_stack, spill, tid);
+    resolve_hit<COUNTERS, false, kWfLdsStack, kBlock>(sv, tab, P.org, P.dir, T.inv_d, lane_id, h, c, pr, lds_stack, spill, tid);
     wf.hit0[i] = make_float4(h.best_t, h.hit_n.x, h.hit_n.y, h.hit_n.z);
     wf.hitp[i] = h.hit_prim;
 }
@@ -1052,17 +1117,25 @@ ORT_D void combine_pixel(const RenderView &rv, unsigned long long idx) {
 /* DIFFUSE: every surface material of the uploaded scene has Ks = Kt = 0, so the evaluation and pdf
    of the specular / transmission lobes are compiled out (sampling keeps all three lobes: a draw of
    exactly 1.0 still takes the reference's transmission branch).  Same values, fewer registers. */
-template <bool COUNTERS, bool DIFFUSE>
+/* the workgroup's copy of the small read-only tables (SceneView::tab_src -> LDS) */
+__device__ __forceinline__ void fill_tab(const SceneView &sv, float4 *lds_tab) {
+    for (int i = (int)threadIdx.x; i < kTabF4; i += (int)blockDim.x) lds_tab[i] = sv.tab_src[i];
+    __syncthreads();
+}
+
+template <bool COUNTERS, bool DIFFUSE, bool TABS>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(ORT_WAVES_PER_EU, ORT_WAVES_PER_EU)))
 pt_persistent(SceneView sv, RenderView rv) {
     __shared__ uint32_t lds_stack[kLdsStack * kBlock];
     __shared__ float lds_focal[3 * kBlock]; /* focal[component][lane] */
+    __shared__ float4 lds_tab[TABS ? kTabF4 : 1];
+    if (TABS) fill_tab(sv, lds_tab);
     const bool prof = COUNTERS && sv.util != nullptr && blockIdx.x < 32u;
     if (prof) {
         if (threadIdx.x < 96) g_lds_prof[threadIdx.x] = 0ull;
         __syncthreads();
     }
-    pt_lane<COUNTERS, DIFFUSE>(sv, rv, lds_stack, lds_focal, (int)threadIdx.x, blockIdx.x * (uint32_t)kBlock + threadIdx.x, prof);
+    pt_lane<COUNTERS, DIFFUSE, TABS>(sv, rv, lds_tab, lds_stack, lds_focal, (int)threadIdx.x, blockIdx.x * (uint32_t)kBlock + threadIdx.x, prof);
     if (prof) {
         __syncthreads();
         if (threadIdx.x < 96 && g_lds_prof[threadIdx.x]) atomicAdd(sv.util + threadIdx.x, g_lds_prof[threadIdx.x]);
@@ -1072,11 +1145,12 @@ pt_persistent(SceneView sv, RenderView rv) {
 /* wavefront kernels: fixed-size grids, grid-stride over the slots */
 template <bool COUNTERS>
 __global__ void __launch_bounds__(kBlock) wf_shade(SceneView sv, RenderView rv, WfView wf, int count_active) {
+    const float4 *lds_tab = nullptr; /* the wavefront kernels read the tables from HBM */
     Counters c;
     unsigned long long produced = 0;
     const uint32_t stride = gridDim.x * (uint32_t)kBlock;
     for (uint32_t i = blockIdx.x * (uint32_t)kBlock + threadIdx.x; i < wf.slots; i += stride)
-        if (wf_shade_slot<COUNTERS>(sv, rv, wf, i, c)) produced++;
+        if (wf_shade_slot<COUNTERS>(sv, rv, lds_tab, wf, i, c)) produced++;
     if (count_active && produced) atomicAdd(wf.active, produced);
     flush_counters(rv, c, COUNTERS);
 }
@@ -1084,12 +1158,13 @@ __global__ void __launch_bounds__(kBlock) wf_shade(SceneView sv, RenderView rv, 
 template <bool COUNTERS>
 __global__ void __launch_bounds__(kBlock) wf_trace(SceneView sv, RenderView rv, WfView wf) {
     __shared__ uint32_t lds_stack[kWfLdsStack * kBlock];
+    const float4 *lds_tab = nullptr;
     uint32_t spill[kWfSpill];
     Counters c;
     const uint32_t stride = gridDim.x * (uint32_t)kBlock;
     const uint32_t lane_id = blockIdx.x * (uint32_t)kBlock + threadIdx.x;
     for (uint32_t i = lane_id; i < wf.slots; i += stride)
-        wf_trace_slot<COUNTERS>(sv, wf, i, lane_id, lds_stack, spill, (int)threadIdx.x, c);
+        wf_trace_slot<COUNTERS>(sv, lds_tab, wf, i, lane_id, lds_stack, spill, (int)threadIdx.x, c);
     flush_counters(rv, c, COUNTERS);
 }
 
@@ -1207,7 +1282,7 @@ void device_release(Scene *scene) {
     if (!d) return;
     (void)hipSetDevice(d->device);
     void *ptrs[] = {d->nodes, d->tris, d->tri_mat, d->spheres, d->sphere_mat, d->boxes, d->box_mat, d->cyls, d->cyl_mat,
-                    d->materials, d->light_is_sphere, d->ref_nodes, d->ref_recs, d->chain_boxes, d->tri_chain, d->sphere_chain,
+                    d->materials, d->light_is_sphere, d->tab, d->ref_nodes, d->ref_recs, d->chain_boxes, d->tri_chain, d->sphere_chain,
                     d->box_chain, d->cyl_chain, d->tri_order, d->sphere_order, d->box_order, d->cyl_order, d->bfs_pool, d->bfs_locks, d->ctrl, d->partial, d->staging, d->jobs, d->states};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -1255,6 +1330,37 @@ int device_upload(Scene *scene, int device, std::string *err) {
     for (size_t i = 0; i < lis.size(); ++i) lis[i] = (scene->lights[i].type == 1u) ? 1u : 0u;
     d->light_count = (uint32_t)lis.size();
     if ((rc = upload_vec(lis, &d->light_is_sphere, err))) return rc;
+    {
+        /* the image of the LDS tables: root node, prologue shapes, light flags, material indices, materials */
+        std::vector<float4> tab((size_t)kTabF4, make_float4(0, 0, 0, 0));
+        uint32_t *tw = (uint32_t *)tab.data();
+        d->tab_flags = 0;
+        if (!t.nodes.empty()) memcpy(&tab[kTabRoot], &t.nodes[0], sizeof(DevNode));
+        if (2u * t.pro_boxes + t.pro_spheres + 4u * t.pro_cyls <= (uint32_t)kTabProCap) {
+            float4 *q = &tab[kTabPro];
+            if (t.pro_boxes) memcpy(q, t.boxes.data(), (size_t)t.pro_boxes * sizeof(DevBox));
+            q += 2u * t.pro_boxes;
+            if (t.pro_spheres) memcpy(q, t.spheres.data(), (size_t)t.pro_spheres * sizeof(DevSphere));
+            q += t.pro_spheres;
+            if (t.pro_cyls) memcpy(q, t.cyls.data(), (size_t)t.pro_cyls * sizeof(DevCyl));
+            d->tab_flags |= TAB_PRO;
+        }
+        if (lis.size() <= (size_t)kTabLightCap) {
+            if (!lis.empty()) memcpy(tw + 4 * kTabLights, lis.data(), lis.size() * 4u);
+            d->tab_flags |= TAB_LIGHTS;
+        }
+        if (t.box_mat.size() <= (size_t)kTabPrimMatCap && t.sphere_mat.size() <= (size_t)kTabPrimMatCap && t.cyl_mat.size() <= (size_t)kTabPrimMatCap) {
+            if (!t.box_mat.empty()) memcpy(tw + 4 * kTabBoxMat, t.box_mat.data(), t.box_mat.size() * 4u);
+            if (!t.sphere_mat.empty()) memcpy(tw + 4 * kTabSphereMat, t.sphere_mat.data(), t.sphere_mat.size() * 4u);
+            if (!t.cyl_mat.empty()) memcpy(tw + 4 * kTabCylMat, t.cyl_mat.data(), t.cyl_mat.size() * 4u);
+            d->tab_flags |= TAB_PRIM_MATS;
+        }
+        if (mats.size() <= (size_t)kTabMatCap) {
+            memcpy(&tab[kTabMats], mats.data(), mats.size() * sizeof(DevMaterial));
+            d->tab_flags |= TAB_MATS;
+        }
+        if ((rc = upload_vec(tab, &d->tab, err))) return rc;
+    }
     const RefTree &rt = scene->ref;
     if ((rc = upload_vec(rt.nodes, &d->ref_nodes, err))) return rc;
     if ((rc = upload_vec(rt.recs, &d->ref_recs, err))) return rc;
@@ -1394,6 +1500,8 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
     sv.cyls = (const float4 *)d->cyls; sv.cyl_mat = (const uint32_t *)d->cyl_mat;
     sv.materials = (const float4 *)d->materials;
     sv.light_is_sphere = (const uint32_t *)d->light_is_sphere;
+    sv.tab_src = (const float4 *)d->tab;
+    sv.tab_flags = d->tab_flags;
     sv.light_count = d->light_count;
     sv.pro_boxes = scene->tree.pro_boxes;
     sv.pro_spheres = scene->tree.pro_spheres;
@@ -1497,10 +1605,16 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
     } else {
         const char *kenv = getenv("ORT_KERNEL"); /* "general" forces the all-lobes kernel (A/B runs; same results) */
         const bool diffuse = d->diffuse_only && !(kenv && strcmp(kenv, "general") == 0);
-        if (counters && diffuse && want_util) hipLaunchKernelGGL((pt_persistent<true, true>), dim3(grid), dim3(kBlock), 0, stream, sv, rv);
-        else if (counters) hipLaunchKernelGGL((pt_persistent<true, false>), dim3(grid), dim3(kBlock), 0, stream, sv, rv);
-        else if (diffuse) hipLaunchKernelGGL((pt_persistent<false, true>), dim3(grid), dim3(kBlock), 0, stream, sv, rv);
-        else hipLaunchKernelGGL((pt_persistent<false, false>), dim3(grid), dim3(kBlock), 0, stream, sv, rv);
+        /* TABS: the scene's small tables all fit their LDS slots (every scene of this repository); otherwise HBM */
+        const uint32_t all_tabs = TAB_PRO | TAB_LIGHTS | TAB_PRIM_MATS | TAB_MATS;
+        const char *tenv = getenv("ORT_LDS_TABLES"); /* "0": read them from HBM anyway (A/B runs; same results) */
+        const bool tabs = (d->tab_flags & all_tabs) == all_tabs && !(tenv && atoi(tenv) == 0);
+#define ORT_LAUNCH(C, D, T) hipLaunchKernelGGL((pt_persistent<C, D, T>), dim3(grid), dim3(kBlock), 0, stream, sv, rv)
+        if (counters && diffuse && want_util) { if (tabs) ORT_LAUNCH(true, true, true); else ORT_LAUNCH(true, true, false); }
+        else if (counters) { if (tabs) ORT_LAUNCH(true, false, true); else ORT_LAUNCH(true, false, false); }
+        else if (diffuse) { if (tabs) ORT_LAUNCH(false, true, true); else ORT_LAUNCH(false, true, false); }
+        else { if (tabs) ORT_LAUNCH(false, false, true); else ORT_LAUNCH(false, false, false); }
+#undef ORT_LAUNCH
         ORT_HIP(hipGetLastError());
     }
     if (rv.mode == JOBS_CHUNK) {

@@ -122,14 +122,14 @@ int main(int argc, char **argv) {
         Counters c;
         for (;;) {
             unsigned long long produced = 0;
-            for (uint32_t i = 0; i < S; ++i) produced += wf_shade_slot<true>(sv, rv, wf, i, c) ? 1 : 0;
+            for (uint32_t i = 0; i < S; ++i) produced += wf_shade_slot<true>(sv, rv, nullptr, wf, i, c) ? 1 : 0;
             if (!produced) break;
-            for (uint32_t i = 0; i < S; ++i) wf_trace_slot<true>(sv, wf, i, 0, wlds.data(), wspill.data(), 0, c);
+            for (uint32_t i = 0; i < S; ++i) wf_trace_slot<true>(sv, nullptr, wf, i, 0, wlds.data(), wspill.data(), 0, c);
         }
         flush_counters(rv, c, true);
     } else
-    if (getenv("SIM_DIFFUSE")) pt_lane<true, true>(sv, rv, lds.data(), lds_focal.data(), 0, 0); /* caller vouches for Ks = Kt = 0 */
-    else pt_lane<true>(sv, rv, lds.data(), lds_focal.data(), 0, 0);
+    if (getenv("SIM_DIFFUSE")) pt_lane<true, true>(sv, rv, nullptr, lds.data(), lds_focal.data(), 0, 0); /* caller vouches for Ks = Kt = 0 */
+    else pt_lane<true>(sv, rv, nullptr, lds.data(), lds_focal.data(), 0, 0); /* TABS = false: the small tables are read from their arrays */
     if (rv.mode == JOBS_CHUNK)
         for (unsigned long long i = 0; i < (unsigned long long)rv.my_blocks * 64; ++i) combine_pixel(rv, i);
     double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
