@@ -30,7 +30,10 @@ namespace ort {
 using namespace ortd;
 
 constexpr int kBlock = 256;      /* 4 waves */
-constexpr int kLdsStack = 24;    /* entries per lane in LDS: 24 * 256 * 4 B = 24 KB per block */
+#ifndef ORT_LDS_STACK
+#define ORT_LDS_STACK 24
+#endif
+constexpr int kLdsStack = ORT_LDS_STACK; /* entries per lane in LDS: 24 * 256 * 4 B = 24 KB per block */
 constexpr int kSpillStack = 40;  /* scratch tail; ort_tree.cpp bounds the depth at 60 */
 constexpr uint32_t kBfsPoolQueues = 256;      /* queues of the breadth-first fallback, shared by all lanes */
 constexpr size_t kBfsPoolBytes = 512u << 20; /* at most; a queue holds one entry per reference-tree node */
@@ -104,6 +107,15 @@ struct RenderView {
     float *partial;  /* nchunks * W*H*3 (CHUNK) */
     unsigned long long *next_job;
     unsigned long long *counters; /* paths rays node_tests tri_tests analytic_tests fallback_rays */
+    /* ray exchange (pt_lane_x): every wave owns two LIFO stashes in HBM, L for parked paths whose ray is still
+       being traversed and R for parked paths whose ray is finished; float4 units */
+    float4 *stash;
+    uint32_t stash_wave_f4; /* per wave: L records 7 * capL, L stacks kLdsStack / 4 * capL, R records 7 * capR */
+    uint32_t capL, capR;
+    uint32_t long_min;   /* start a traversal phase on parked rays when tracing lanes + parked rays reach this */
+    uint32_t long_refill; /* within such a phase, take more parked rays when fewer lanes than this are tracing */
+    uint32_t inflight_cap; /* a lane without a path starts a new job only while the wave holds fewer parked paths than this
+                              (every parked path is a job in progress: the more a wave holds, the longer its tail) */
 };
 
 /* wavefront mode: per-slot path state in HBM, structure-of-arrays so that a wave's loads and
@@ -148,6 +160,8 @@ struct DeviceScene {
     size_t states_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int cu_count = 0;
+    void *stash = nullptr; /* ray exchange: the waves' stashes */
+    size_t stash_bytes = 0;
     void *wf_mem = nullptr; /* wavefront state, carved into the WfView arrays */
     size_t wf_bytes = 0;
     unsigned long long *h_active = nullptr; /* pinned */
@@ -206,18 +220,20 @@ enum : int { PS_NEED_JOB = 0, PS_PIXEL = 1, PS_SAMPLE = 2, PS_HIT = 3, PS_DONE =
         if (COUNTERS && (pr).on) {                                                                   \
             const unsigned long long now_ = __builtin_amdgcn_s_memtime();                            \
             const unsigned long long m_ = __ballot(pred), a_ = __ballot(true);                       \
+            /* the wave's previous mark lives in LDS: a register would only be updated in the lanes active there */ \
+            unsigned long long *last_ = &g_lds_prof[96 + (threadIdx.x >> 6)];                        \
             if ((int)__lane_id() == __ffsll(a_) - 1) {                                               \
-                atomicAdd(&g_lds_prof[32 + 3 * (k)], now_ - (pr).t);                                 \
+                atomicAdd(&g_lds_prof[32 + 3 * (k)], now_ - *last_);                                 \
                 atomicAdd(&g_lds_prof[32 + 3 * (k) + 1], 1ull);                                      \
                 atomicAdd(&g_lds_prof[32 + 3 * (k) + 2], (unsigned long long)__popcll(m_));          \
+                *last_ = __builtin_amdgcn_s_memtime();                                               \
             }                                                                                        \
-            (pr).t = __builtin_amdgcn_s_memtime();                                                   \
         }                                                                                            \
     } while (0)
 #endif
 
 #ifndef ORT_HOST_SIM
-__shared__ unsigned long long g_lds_prof[96]; /* diagnostics build only: [0,32) event probes, [32,96) phase timers */
+__shared__ unsigned long long g_lds_prof[96 + 4]; /* + the four waves' previous marks */ /* diagnostics build only: [0,32) event probes, [32,96) phase timers */
 #endif
 
 struct Prof { unsigned long long t = 0; bool on = false; };
@@ -1031,6 +1047,194 @@ ORT_D void pt_lane(const SceneView &sv, const RenderView &rv, const float4 *tab,
     flush_counters(rv, c, COUNTERS);
 }
 
+
+#ifndef ORT_HOST_SIM
+/* ---- ray exchange: whole waves shade, whole waves traverse --------------------------------------------------
+ * The plain loop (pt_lane) leaves the traversal loop when fewer than refill_below lanes are still tracing; those
+ * stragglers then sit idle through the whole shading pass, and the next traversal loop runs for them and the few
+ * new rays that need more than the root.  Here the stragglers are PARKED instead: path, hit and traversal state
+ * (28 dwords) plus the used part of the LDS stack go to the wave's own L stash in HBM, and the lane takes a parked
+ * path whose ray is finished (R stash) or a new job, so that the shading pass runs with all 64 lanes.  When enough
+ * rays are parked, the wave parks its finished paths in R, fills ALL lanes from L and traverses -- 64 rays of the
+ * expensive kind together, topping up from L as they finish.  Path state travels with the ray, seeds belong to
+ * jobs, so which lane or in which order a path is advanced cannot change a bit of the result.
+ * Both stashes are private to the wave (wave-uniform tops, ballot-prefix slots): no atomics, no barriers. */
+struct Stash {
+    float4 *rec;    /* [7][cap] */
+    uint32_t *stk;  /* [kLdsStack][cap], L only */
+    uint32_t cap;
+};
+
+ORT_D uint32_t lane_rank(unsigned long long mask) { /* set bits of mask below this lane */
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+constexpr uint32_t kStashVecs = 9u; /* float4 per parked path */
+ORT_D void stash_store(const Stash &st, uint32_t slot, const PathState &P, const HitState &h, uint32_t cur, int sp, V3 inv_d, const float *focal_cache) {
+    float4 *r = st.rec + slot;
+    const uint32_t cap = st.cap;
+    r[0] = make_float4(P.org.x, P.org.y, P.org.z, P.dir.x);
+    r[cap] = make_float4(P.dir.y, P.dir.z, h.best_t, om_bits_f32(h.hit_prim));
+    r[2u * cap] = make_float4(h.hit_n.x, h.hit_n.y, h.hit_n.z, h.phantom_t);
+    r[3u * cap] = make_float4(h.runner_t, om_bits_f32(cur), om_bits_f32((uint32_t)sp), om_bits_f32(P.rng));
+    r[4u * cap] = make_float4(P.color.x, P.color.y, P.color.z, P.weight.x);
+    r[5u * cap] = make_float4(P.weight.y, P.weight.z, P.wo.x, P.wo.y);
+    r[6u * cap] = make_float4(P.wo.z, om_bits_f32(P.pxy), om_bits_f32(P.jyp), om_bits_f32(P.sample | (P.primary ? 0x80000000u : 0u)));
+    /* 1/d and the pixel's focal point travel too: recomputing them costs more than two more stores and loads */
+    r[7u * cap] = make_float4(inv_d.x, inv_d.y, inv_d.z, focal_cache[0]);
+    r[8u * cap] = make_float4(focal_cache[kBlock], focal_cache[2 * kBlock], 0.0f, 0.0f);
+}
+
+ORT_D void stash_load(const Stash &st, uint32_t slot, const RenderView &rv, PathState &P, HitState &h, Trav &T, float *focal_cache) {
+    const float4 *r = st.rec + slot;
+    const uint32_t cap = st.cap;
+    const float4 a = r[0], b = r[cap], c = r[2u * cap], d = r[3u * cap], e = r[4u * cap], f = r[5u * cap], g = r[6u * cap];
+    const float4 i = r[7u * cap], j = r[8u * cap];
+    P.org = mk(a.x, a.y, a.z); P.dir = mk(a.w, b.x, b.y);
+    h.best_t = b.z; h.hit_prim = om_f32_bits(b.w);
+    h.hit_n = mk(c.x, c.y, c.z); h.phantom_t = c.w;
+    h.runner_t = d.x; T.cur = om_f32_bits(d.y); T.sp = (int)om_f32_bits(d.z); P.rng = om_f32_bits(d.w);
+    P.color = mk(e.x, e.y, e.z); P.weight = mk(e.w, f.x, f.y); P.wo = mk(f.z, f.w, g.x);
+    P.pxy = om_f32_bits(g.y); P.jyp = om_f32_bits(g.z);
+    const uint32_t sm = om_f32_bits(g.w);
+    P.sample = sm & 0x7fffffffu; P.primary = (sm >> 31) != 0u;
+    P.jxx = (P.pxy & 0xffffu) | (((P.pxy & 0xffffu) + 1u) << 16); /* implicit jobs are single pixels */
+    P.spp = (rv.mode == JOBS_PIXEL) ? rv.spp : rv.chunk;
+    P.job_index = 0;
+    P.ps = PS_HIT;
+    T.inv_d = mk(i.x, i.y, i.z);
+    focal_cache[0] = i.w; focal_cache[kBlock] = j.x; focal_cache[2 * kBlock] = j.y;
+}
+
+template <bool COUNTERS, bool DIFFUSE, bool TABS>
+ORT_D void pt_lane_x(const SceneView &sv, const RenderView &rv, const float4 *tab, uint32_t *lds_stack, float *lds_focal, const int tid,
+                     const uint32_t lane_id, bool prof_on) {
+    uint32_t spill[kSpillStack];
+    Prof pr;
+    pr.on = prof_on;
+    if (COUNTERS && prof_on) pr.t = __builtin_amdgcn_s_memtime();
+    PathState P;
+    HitState h;
+    Trav T;
+    Counters c;
+    bool tracing = false;
+
+    const uint32_t wave = lane_id >> 6;
+    float4 *wbase = rv.stash + (size_t)wave * rv.stash_wave_f4;
+    Stash L, R;
+    L.rec = wbase; L.cap = rv.capL;
+    L.stk = (uint32_t *)(wbase + kStashVecs * rv.capL);
+    R.rec = wbase + (kStashVecs + (uint32_t)kLdsStack / 4u) * rv.capL; R.cap = rv.capR; R.stk = nullptr;
+    uint32_t ltop = 0, rtop = 0; /* wave-uniform */
+    float *focal_cache = lds_focal + tid;
+
+    for (;;) {
+        /* ---- exchange: every lane is tracing (unfinished ray), done (finished ray, PS_HIT) or free (no path) ---- */
+        const unsigned long long m_tr = __ballot(tracing);
+        const unsigned long long m_done = __ballot(!tracing && P.ps == PS_HIT);
+        const unsigned long long m_free = ~(m_tr | m_done);
+        const uint32_t n_tr = (uint32_t)__popcll(m_tr), n_free = (uint32_t)__popcll(m_free);
+        /* nothing left but parked rays: traverse them however few */
+        const bool drain = m_tr == 0ull && m_done == 0ull && rtop == 0u && __ballot(P.ps != PS_DONE) == 0ull;
+        /* once the job space is empty nothing is parked any more (every parked path is a job some lane still has to
+           finish): lanes without a path take parked ones, finished rays first, and everything else carries on */
+        const bool endgame = __ballot(P.ps == PS_DONE) != 0ull;
+        bool long_phase = !endgame && ltop > 0u && (n_tr + ltop >= rv.long_min || drain);
+        if (endgame) {
+            const bool is_free = !tracing && P.ps != PS_HIT;
+            const unsigned long long m_recv = __ballot(is_free);
+            const uint32_t rrank = lane_rank(m_recv);
+            const bool take_r = is_free && rrank < rtop;
+            const bool take_l = is_free && !take_r && rrank - rtop < ltop;
+            if (take_r) stash_load(R, rtop - 1u - rrank, rv, P, h, T, focal_cache);
+            if (take_l) {
+                const uint32_t slot = ltop - 1u - (rrank - rtop);
+                stash_load(L, slot, rv, P, h, T, focal_cache);
+                for (int lv = 0; lv < T.sp; ++lv) lds_stack[lv * kBlock + tid] = L.stk[(uint32_t)lv * L.cap + slot];
+                tracing = true;
+            }
+            uint32_t n_recv = (uint32_t)__popcll(m_recv);
+            const uint32_t from_r = n_recv < rtop ? n_recv : rtop;
+            rtop -= from_r;
+            n_recv -= from_r;
+            ltop -= n_recv < ltop ? n_recv : ltop;
+        } else if (long_phase) {
+            /* fill the lanes that are not tracing with parked rays; finished paths make room by parking in R */
+            uint32_t want = 64u - n_tr;
+            if (want > ltop) want = ltop;
+            uint32_t need_done = want > n_free ? want - n_free : 0u;
+            if (need_done > R.cap - rtop) need_done = R.cap - rtop;
+            const bool is_done = !tracing && P.ps == PS_HIT;
+            const uint32_t drank = lane_rank(m_done);
+            const bool park = is_done && drank < need_done;
+            if (park) { stash_store(R, rtop + drank, P, h, 0u, 0, T.inv_d, focal_cache); P.ps = PS_NEED_JOB; }
+            rtop += need_done < (uint32_t)__popcll(m_done) ? need_done : (uint32_t)__popcll(m_done);
+            const bool is_free = !tracing && P.ps != PS_HIT; /* includes the lanes that parked just now */
+            const unsigned long long m_recv = __ballot(is_free);
+            const uint32_t rrank = lane_rank(m_recv);
+            const bool take = is_free && rrank < ltop;
+            if (take) {
+                const uint32_t slot = ltop - 1u - rrank;
+                stash_load(L, slot, rv, P, h, T, focal_cache);
+                for (int lv = 0; lv < T.sp; ++lv) lds_stack[lv * kBlock + tid] = L.stk[(uint32_t)lv * L.cap + slot];
+                tracing = true;
+            }
+            const uint32_t n_recv = (uint32_t)__popcll(m_recv);
+            ltop -= n_recv < ltop ? n_recv : ltop;
+            /* no lane could take a ray (R full, so no finished path could make room) and none is tracing: shade
+               instead, which frees lanes */
+            if (n_tr == 0u && __ballot(take) == 0ull) long_phase = false;
+        } else {
+            /* park the stragglers (their stack tail must be in LDS), then hand the free lanes parked finished paths */
+            const bool can_park = tracing && T.sp <= kLdsStack;
+            const unsigned long long m_park = __ballot(can_park);
+            const uint32_t prank = lane_rank(m_park);
+            const bool park = can_park && ltop + prank < L.cap;
+            if (park) {
+                const uint32_t slot = ltop + prank;
+                stash_store(L, slot, P, h, T.cur, T.sp, T.inv_d, focal_cache);
+                for (int lv = 0; lv < T.sp; ++lv) L.stk[(uint32_t)lv * L.cap + slot] = lds_stack[lv * kBlock + tid];
+                tracing = false;
+                P.ps = PS_NEED_JOB;
+            }
+            {
+                const uint32_t n_park = (uint32_t)__popcll(m_park), room = L.cap - ltop;
+                ltop += n_park < room ? n_park : room;
+            }
+            const bool is_free = !tracing && P.ps != PS_HIT;
+            const unsigned long long m_recv = __ballot(is_free);
+            const uint32_t rrank = lane_rank(m_recv);
+            const bool take = is_free && rrank < rtop;
+            if (take) {
+                stash_load(R, rtop - 1u - rrank, rv, P, h, T, focal_cache);
+            }
+            const uint32_t n_recv = (uint32_t)__popcll(m_recv);
+            rtop -= n_recv < rtop ? n_recv : rtop;
+        }
+        /* ---- shade: only outside a traversal phase, so that it runs with (nearly) all lanes ---- */
+        const bool hold = P.ps == PS_NEED_JOB && ltop + rtop >= rv.inflight_cap; /* no new job for now */
+        if (!long_phase && !tracing && !hold) {
+            ORT_UTIL(sv, 3, true);
+            ORT_UTIL(sv, 4, P.ps == PS_HIT);
+            ORT_PHASE(pr, sv, 7, true);
+            if (P.ps == PS_HIT) resolve_hit<COUNTERS, TABS, kLdsStack, kBlock>(sv, tab, P.org, P.dir, T.inv_d, lane_id, h, c, pr, lds_stack, spill, tid);
+            ORT_PHASE(pr, sv, 0, P.ps == PS_HIT);
+            tracing = produce_ray<COUNTERS, DIFFUSE, TABS>(sv, rv, tab, P, h, c, pr, focal_cache, kBlock);
+            if (tracing) {
+                begin_ray<COUNTERS, TABS, kLdsStack, kBlock>(sv, tab, P, T, h, c, pr, lds_stack, spill, tid);
+                if (COUNTERS) c.rays++;
+            }
+        }
+        if (__ballot(P.ps != PS_DONE || tracing) == 0ull && ltop == 0u && rtop == 0u) break;
+        /* in a traversal phase come back for more parked rays when half the lanes have finished; otherwise (and once
+           L is empty) when only stragglers are left, which then park */
+        const int below = (long_phase && ltop > 0u) ? (int)rv.long_refill : rv.refill_below;
+        if (tracing) tracing = traverse<COUNTERS, kLdsStack, kBlock>(sv, P.org, P.dir, T, h, lds_stack, spill, tid, below, rv.descend_below, c, pr);
+    }
+    flush_counters(rv, c, COUNTERS);
+}
+#endif /* !ORT_HOST_SIM */
+
 /* ---- wavefront mode -------------------------------------------------------------------------- */
 constexpr uint32_t WF_PRIMARY = 8u, WF_HAS_RAY = 16u;
 constexpr int kWfLdsStack = 16; /* trace kernel: 16 LDS entries per lane (16 KB per 256-lane block), tail in scratch */
@@ -1133,9 +1337,31 @@ pt_persistent(SceneView sv, RenderView rv) {
     const bool prof = COUNTERS && sv.util != nullptr && blockIdx.x < 32u;
     if (prof) {
         if (threadIdx.x < 96) g_lds_prof[threadIdx.x] = 0ull;
+        if (threadIdx.x < 4) g_lds_prof[96 + threadIdx.x] = __builtin_amdgcn_s_memtime();
         __syncthreads();
     }
     pt_lane<COUNTERS, DIFFUSE, TABS>(sv, rv, lds_tab, lds_stack, lds_focal, (int)threadIdx.x, blockIdx.x * (uint32_t)kBlock + threadIdx.x, prof);
+    if (prof) {
+        __syncthreads();
+        if (threadIdx.x < 96 && g_lds_prof[threadIdx.x]) atomicAdd(sv.util + threadIdx.x, g_lds_prof[threadIdx.x]);
+    }
+}
+
+/* the same with the ray exchange (pt_lane_x): implicit job spaces only, LDS tables required */
+template <bool COUNTERS, bool DIFFUSE>
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(ORT_WAVES_PER_EU, ORT_WAVES_PER_EU)))
+pt_persistent_x(SceneView sv, RenderView rv) {
+    __shared__ uint32_t lds_stack[kLdsStack * kBlock];
+    __shared__ float lds_focal[3 * kBlock];
+    __shared__ float4 lds_tab[kTabF4];
+    fill_tab(sv, lds_tab);
+    const bool prof = COUNTERS && sv.util != nullptr && blockIdx.x < 32u;
+    if (prof) {
+        if (threadIdx.x < 96) g_lds_prof[threadIdx.x] = 0ull;
+        if (threadIdx.x < 4) g_lds_prof[96 + threadIdx.x] = __builtin_amdgcn_s_memtime();
+        __syncthreads();
+    }
+    pt_lane_x<COUNTERS, DIFFUSE, true>(sv, rv, lds_tab, lds_stack, lds_focal, (int)threadIdx.x, blockIdx.x * (uint32_t)kBlock + threadIdx.x, prof);
     if (prof) {
         __syncthreads();
         if (threadIdx.x < 96 && g_lds_prof[threadIdx.x]) atomicAdd(sv.util + threadIdx.x, g_lds_prof[threadIdx.x]);
@@ -1287,6 +1513,7 @@ void device_release(Scene *scene) {
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (d->wf_mem) (void)hipFree(d->wf_mem);
+    if (d->stash) (void)hipFree(d->stash);
     if (d->h_active) (void)hipHostFree(d->h_active);
     if (d->ev0) (void)hipEventDestroy(d->ev0);
     if (d->ev1) (void)hipEventDestroy(d->ev1);
@@ -1384,7 +1611,7 @@ int device_upload(Scene *scene, int device, std::string *err) {
     {
         const char *e = getenv("ORT_BLOCKS_PER_CU"); /* tuning knob: resident workgroups per CU (4 = one wave per SIMD each) */
         unsigned int per_cu = e ? (unsigned int)atoi(e) : 4u;
-        if (per_cu < 1u || per_cu > 4u) per_cu = 4u;
+        if (per_cu < 1u || per_cu > 8u) per_cu = 4u;
         d->max_blocks = (unsigned int)(d->cu_count > 0 ? d->cu_count : 256) * per_cu;
     }
     /* fallback queues: one entry per reference-tree node each, as many as fit the budget */
@@ -1610,6 +1837,28 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
         const char *tenv = getenv("ORT_LDS_TABLES"); /* "0": read them from HBM anyway (A/B runs; same results) */
         const bool tabs = (d->tab_flags & all_tabs) == all_tabs && !(tenv && atoi(tenv) == 0);
 #define ORT_LAUNCH(C, D, T) hipLaunchKernelGGL((pt_persistent<C, D, T>), dim3(grid), dim3(kBlock), 0, stream, sv, rv)
+        /* ray exchange (pt_lane_x): opt-in with ORT_EXCHANGE=1 -- bit-identical, 60 of 64 lanes in the shading
+           pass instead of 53 and leaf visits four times better filled, but the parking traffic and 20 more spilled
+           registers cost what that gains (profiles/r02_tuning.md); implicit job spaces with the LDS tables only */
+        const char *xenv = getenv("ORT_EXCHANGE");
+        const bool exch = tabs && rv.mode != JOBS_EXPLICIT && (xenv && atoi(xenv) != 0) && (!counters || (want_util && diffuse));
+        if (exch) {
+            const char *e;
+            rv.capL = 128; rv.capR = 192;
+            rv.long_min = (e = getenv("ORT_LONG_MIN")) ? (uint32_t)atoi(e) : 64u;
+            rv.long_refill = (e = getenv("ORT_LONG_REFILL")) ? (uint32_t)atoi(e) : 32u;
+            rv.inflight_cap = (e = getenv("ORT_INFLIGHT_CAP")) ? (uint32_t)atoi(e) : 64u;
+            if (rv.long_min < 1u) rv.long_min = 1u;
+            if (rv.long_min > rv.capL) rv.long_min = rv.capL;
+            if (rv.long_refill > 64u) rv.long_refill = 64u;
+            rv.stash_wave_f4 = (kStashVecs + (uint32_t)kLdsStack / 4u) * rv.capL + kStashVecs * rv.capR;
+            const size_t need = (size_t)d->max_blocks * (kBlock / 64) * rv.stash_wave_f4 * sizeof(float4);
+            if ((rc = ensure(&d->stash, &d->stash_bytes, need, err))) return rc;
+            rv.stash = (float4 *)d->stash;
+            if (counters) hipLaunchKernelGGL((pt_persistent_x<true, true>), dim3(grid), dim3(kBlock), 0, stream, sv, rv); /* diagnostics: probes of the diffuse flavour */
+            else if (diffuse) hipLaunchKernelGGL((pt_persistent_x<false, true>), dim3(grid), dim3(kBlock), 0, stream, sv, rv);
+            else hipLaunchKernelGGL((pt_persistent_x<false, false>), dim3(grid), dim3(kBlock), 0, stream, sv, rv);
+        } else
         if (counters && diffuse && want_util) { if (tabs) ORT_LAUNCH(true, true, true); else ORT_LAUNCH(true, true, false); }
         else if (counters) { if (tabs) ORT_LAUNCH(true, false, true); else ORT_LAUNCH(true, false, false); }
         else if (diffuse) { if (tabs) ORT_LAUNCH(false, true, true); else ORT_LAUNCH(false, true, false); }
