@@ -11,9 +11,20 @@ bunny.ply (69 451 triangles) in a closed room, 1920x1080, 1024 spp, rr 0.8 -- on
 sharded by 8x8-pixel blocks over the N GPUs (total work fixed => "strong" scaling).
 
 Prints ONE JSON line on rank 0 with the contract fields plus
-  roofline     : algorithmic bytes (SURVEY 8d formula, exact device counters) / kernel time
+  roofline     : the contract's figure -- algorithmic bytes (SURVEY 8d formula, exact device
+                 counters) / kernel time against the 8 TB/s HBM peak -- and, next to it, what
+                 the kernel is really bound by: `frac_divergent` (the same without the bytes of
+                 the analytic prologue, which are wave-uniform reads served from LDS, not memory
+                 traffic), `measured_hbm_gbs` / `traffic` (rocprofv3 PMC of this very kernel
+                 source, quoted only while profiles/r02_pmc_stamp.json carries the hash of the
+                 kernel sources that are being run), `lanes_active` and `valu_issue_frac` (same
+                 stamp).  The path is bound by VALU issue at ~50 % lane utilisation and by memory
+                 latency; measured HBM traffic is ~1 % of the peak.
   cpu_baseline : the reference's own code (oracle/_ref, kind "reference") or the oracle
                  (kind "port") timed on this host's cores on a bounded sample; N=1 only.
+
+  --policy tile32 renders with main()'s own schedule instead (macos_main.mm:602-662: 1024 tiles,
+  one serial RNG stream each = 1024 GPU lanes): what the reference's caller costs on a GPU.
 """
 import argparse
 import json
@@ -39,6 +50,8 @@ def parse_args():
     ap.add_argument("--spp", type=int, default=1024)
     ap.add_argument("--chunk", type=int, default=64)
     ap.add_argument("--seed", type=int, default=12345)
+    ap.add_argument("--policy", default="chunk", choices=["chunk", "pixel", "tile32"],
+                    help="seeding policy = the caller side of the reference call (include/ort.h); tile32 is main()'s schedule")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-spp", type=int, default=96)
     return ap.parse_args()
@@ -99,6 +112,30 @@ def cpu_baseline(args, scene_path):
             "sample": sample + "; oracle/liboracle.so (plain-C restatement), pthreads"}
 
 
+def kernel_source_hash():
+    """SHA-256 over the sources the HIP kernels are built from: ties a PMC stamp to the code it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "offline_raytracer_amd", "csrc")
+    for name in ("ort_kernels.hip", "ort_device.h", "ort_detmath.h", "ort_scene.h"):
+        with open(os.path.join(d, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_stamp(workload_key):
+    """profiles/r02_pmc_stamp.json (tools/make_pmc_stamp.py, from a rocprofv3 --pmc run of this workload):
+    returned only if it was measured on the kernel sources that are in the tree now."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_stamp.json")
+    try:
+        st = json.load(open(path))
+    except Exception:
+        return None
+    if st.get("kernel_hash") != kernel_source_hash() or st.get("workload_key") != workload_key:
+        return None
+    return st
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -139,11 +176,41 @@ def main():
         scene_path = os.path.join(ROOT, "data", args.scene + ".scn")
     scene = api.Scene.load_scn(scene_path).commit().upload(device_index)
     W, H = args.width, args.height
-    fb = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
-    params = api.Scene.params(W, H, args.spp, args.seed, "chunk", chunk=args.chunk, shard=(rank, world))
+    if args.policy == "tile32" and world > 1:
+        sys.exit("bench.py --policy tile32 is a one-GPU line: main()'s 1024 serial tiles do not shard by blocks")
     stream = torch.cuda.current_stream().cuda_stream
+    chunk = args.chunk if args.policy == "chunk" else 0
+    # The step: this rank renders ITS 8x8 blocks into a packed buffer (1/N of a frame; the CHUNK partial sums use the
+    # same layout) and ONE collective assembles the frame on rank 0 -- ort_gather_framebuffer: grouped ncclSend/ncclRecv
+    # over RCCL + an un-permute kernel, all inside libort.so.  If RCCL cannot be brought up from C++ (or in the
+    # one-GPU rehearsal mode) the blocks travel through torch.distributed instead; `gather` in the line says which.
+    sharded, gather_impl = None, "none (1 GPU): un-permute kernel only"
+    if args.policy != "tile32":
+        try:
+            if share_gpu and world > 1:
+                raise RuntimeError("rehearsal mode: RCCL refuses two ranks on one device")
+            sharded = odist.ShardedRenderer(scene, W, H, rank, world, device_index)
+            if world > 1:
+                gather_impl = "ort_gather_framebuffer (C++: RCCL ncclSend/ncclRecv group + un-permute kernel)"
+        except Exception as e:  # noqa: BLE001 -- any failure to bring RCCL up must not lose the measurement
+            sharded = None
+            gather_impl = "torch.distributed.gather of packed blocks (C++ RCCL path unavailable: %s)" % str(e)[:120]
+        if world > 1:  # all ranks must take the same path
+            ok = torch.tensor([1 if sharded is not None else 0], device=torch.device("cpu") if share_gpu else dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                sharded = None
+    fb = sharded.full if (sharded is not None and rank == 0) else torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+    if sharded is not None:
+        params = sharded.params(args.spp, args.seed, args.policy, chunk=chunk)
+    else:
+        params = api.Scene.params(W, H, args.spp, args.seed, args.policy, chunk=chunk, shard=(rank, world))
 
     def step(want_stats=False):
+        if sharded is not None:
+            st = sharded.render(params, stream=stream, want_stats=want_stats)
+            sharded.gather(stream=stream)
+            return st
         st = scene.render_device(fb.data_ptr(), params, stream=stream, want_stats=want_stats)
         if world > 1:
             if share_gpu:
@@ -179,26 +246,28 @@ def main():
 
     # algorithmic bytes per path from exact device counters (untimed counters build of the same
     # kernel, same scene/seed/policy at reduced spp: the per-path averages are spp-independent)
-    cparams = api.Scene.params(W, H, args.chunk, args.seed, "chunk", chunk=args.chunk, counters=True, shard=(rank, world))
-    cst = scene.render_device(fb.data_ptr(), cparams, stream=stream, want_stats=True)
+    cspp = args.chunk if args.policy == "chunk" else min(args.spp, 4)
+    cparams = api.Scene.params(W, H, cspp, args.seed, args.policy, chunk=chunk, counters=True, shard=(rank, world))
+    cfb = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+    cst = scene.render_device(cfb.data_ptr(), cparams, stream=stream, want_stats=True)
     R = cst["rays"] / max(1, cst["paths"])
     Vn = cst["node_tests"] / max(1, cst["rays"])
     Vt = cst["tri_tests"] / max(1, cst["rays"])
     Vp = cst["analytic_tests"] / max(1, cst["rays"])
     bytes_per_path = R * (Vn * 32.0 + Vt * 36.0 + Vp * 32.0) + 12.0 / args.spp
+    # the analytic prologue's shape records are read once per workgroup into LDS and broadcast: they are not memory
+    # traffic in any physical sense.  Counting only divergent reads (tree nodes, triangles, analytic shapes IN the tree):
+    pro = scene.tree_info().get("prologue_prims", 0)
+    bytes_per_path_divergent = R * (Vn * 32.0 + Vt * 36.0 + max(0.0, Vp - pro) * 32.0) + 12.0 / args.spp
     my_paths = paths_per_step / world  # per launch on this rank (blocks are dealt round-robin)
     k_ms = sum(kernel_ms) / len(kernel_ms)
     achieved = bytes_per_path * my_paths / (k_ms * 1e-3) / 1e9
-    # measured HBM bytes per launch come from a separate rocprofv3 --pmc run of THIS step (the profiler
-    # cannot be attached from inside): only quoted when the configuration is the profiled one
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    profiled = (world == 1 and args.scene == "c3_bunny_room" and (W, H, args.spp, args.chunk) == (1920, 1080, 1024, 64))
-    if profiled and os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get("bytes_per_launch")
-        except Exception:
-            traffic = None
+    # measured figures come from a separate rocprofv3 --pmc run of THIS step (the profiler cannot be attached from
+    # inside); they are quoted only while the stamp matches the kernel sources in the tree and the workload
+    workload_key = "%s %dx%d %dspp %s%d x%d" % (args.scene, W, H, args.spp, args.policy, args.chunk if args.policy == "chunk" else 0, world)
+    stamp = pmc_stamp(workload_key)
+    traffic = stamp.get("hbm_bytes_per_launch") if stamp else None
+    achieved_divergent = bytes_per_path_divergent * my_paths / (k_ms * 1e-3) / 1e9
 
     if rank == 0:
         line = {
@@ -207,11 +276,22 @@ def main():
             "vs_baseline": None, "dtype": "f32",
             "data": "synthetic: build-authored closed-room .scn around %s, fixed seed %d"
                     % ("a generated height-field mesh" if args.scene.startswith("c5_") else "the reference's mesh files", args.seed),
-            "config": {"workload": "%s.scn (%d triangles) %dx%d %dspp rr0.8, CHUNK policy chunk=%d, "
-                                   "one frame sharded in 8x8 blocks over %d GPU(s)" % (args.scene, scene.info().triangle_count, W, H, args.spp, args.chunk, world),
-                       "width": W, "height": H, "spp": args.spp, "paths_per_step": paths_per_step},
+            "config": {"workload": "%s.scn (%d triangles) %dx%d %dspp rr0.8, %s, "
+                                   "one frame sharded in 8x8 blocks over %d GPU(s)" % (args.scene, scene.info().triangle_count, W, H, args.spp,
+                                   ("CHUNK policy chunk=%d" % args.chunk) if args.policy == "chunk" else
+                                   ("TILE32 policy: main()'s 1024 tiles, one serial stream each" if args.policy == "tile32" else "PIXEL policy"), world),
+                       "width": W, "height": H, "spp": args.spp, "paths_per_step": paths_per_step, "gather": gather_impl,
+                       "workspace_bytes_per_rank": api.workspace_bytes(params)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac_divergent": achieved_divergent / HBM_PEAK_GBS, "bytes_per_path_divergent": bytes_per_path_divergent,
+                         "measured_hbm_gbs": (traffic / (k_ms * 1e-3) / 1e9) if traffic else None,
+                         "measured_frac": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                         "lanes_active": stamp.get("lanes_active") if stamp else None,
+                         "valu_issue_frac": stamp.get("valu_issue_frac") if stamp else None,
+                         "limiter": "VALU issue at partial lane utilisation + memory latency; not HBM bandwidth (scene is L2 / Infinity-Cache resident)",
+                         "pmc_stamp": ({"kernel_hash": stamp["kernel_hash"], "git_commit": stamp.get("git_commit"), "source": stamp.get("source")} if stamp else None),
+                         "kernel_hash": kernel_source_hash(),
                          "kernel": "pt_persistent", "kernel_ms": k_ms, "bytes_per_path": bytes_per_path,
                          "rays_per_path": R, "node_tests_per_ray": Vn, "tri_tests_per_ray": Vt,
                          "analytic_tests_per_ray": Vp, "fallback_rays": cst["fallback_rays"]},

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define ORT_ABI_VERSION 1
+#define ORT_ABI_VERSION 2
 
 enum {
     ORT_OK = 0,
@@ -193,7 +193,11 @@ int ort_tiled_raytrace_batch(ort_scene *scene, float *out_rgb, int32_t width, in
  * Results are independent of how pixels are spread over lanes, workgroups or GPUs. */
 enum { ORT_POLICY_TILE32 = 0, ORT_POLICY_WHOLE = 1, ORT_POLICY_PIXEL = 2, ORT_POLICY_CHUNK = 3 };
 
-enum { ORT_RENDER_COUNTERS = 1 }; /* flags */
+/* flags.  ORT_RENDER_PACKED (PIXEL / CHUNK policies): the output buffer holds only this shard's 8x8 blocks,
+   [local block k][pixel in block, row-major 8x8][rgb] with k-th block = block id shard_index + k * shard_count of
+   the row-major block grid (ceil(W/8) wide, row 0 = bottom); ort_shard_block_count blocks, 768 B each.  That is
+   the layout ort_gather_framebuffer moves between GPUs. */
+enum { ORT_RENDER_COUNTERS = 1, ORT_RENDER_PACKED = 2 };
 
 typedef struct {
     int32_t width, height;
@@ -220,8 +224,40 @@ int ort_render_image(ort_scene *scene, const ort_render_params *params, float *o
 int ort_render_image_device(ort_scene *scene, const ort_render_params *params, void *d_out_rgb, void *hip_stream,
                             ort_stats *stats);
 
-/* bytes of device workspace ort_render_image_device keeps for these params (CHUNK partial sums) */
+/* bytes of device workspace ort_render_image_device keeps for these params (CHUNK partial sums, held in the packed
+   block layout: a shard keeps 1/shard_count of a frame per chunk) */
 int ort_render_workspace_bytes(const ort_render_params *params, uint64_t *bytes);
+
+/* ---- multi-GPU: block sharding and the one collective -------------------------------------
+ * Replaces main()'s shared-memory tile pool (macos_main.mm:565-671: eight pthreads, one queue, one framebuffer)
+ * across the GPUs of a node: scene replicated, 8x8 blocks dealt round-robin, every rank renders its blocks into a
+ * packed buffer (ORT_RENDER_PACKED) and ONE gather brings them to rank 0 -- grouped ncclSend / ncclRecv over RCCL
+ * (xGMI), then an un-permute kernel on rank 0.  Seeds are per pixel, so the assembled image is bit-identical to a
+ * one-GPU render.  librccl.so is loaded on first use. */
+int ort_shard_block_count(int32_t width, int32_t height, uint32_t shard_index, uint32_t shard_count, uint64_t *blocks);
+/* host-side (CPU) packing, for callers that move the blocks themselves */
+int ort_pack_blocks_host(const float *full_rgb, int32_t width, int32_t height, uint32_t shard_index, uint32_t shard_count, float *packed);
+int ort_unpack_blocks_host(const float *packed, int32_t width, int32_t height, uint32_t shard_index, uint32_t shard_count, float *full_rgb);
+/* device-side un-permute of one shard's packed blocks into a full frame (both DEVICE pointers) */
+int ort_unpack_blocks_device(const void *d_packed, int32_t width, int32_t height, uint32_t shard_index, uint32_t shard_count,
+                             void *d_full_rgb, void *hip_stream);
+
+typedef struct ort_comm ort_comm;
+#define ORT_COMM_ID_BYTES 128
+/* one process per GPU: rank 0 draws an id (ncclGetUniqueId), hands it to the other ranks by any means, then every
+   rank creates its communicator on its device.  world == 1 needs no id and never touches RCCL. */
+int ort_comm_unique_id(void *id /* ORT_COMM_ID_BYTES */);
+int ort_comm_create(const void *id, int rank, int world, int device, ort_comm **out);
+/* one process driving all GPUs (ncclCommInitAll): fills out[0 .. world) */
+int ort_comm_create_local(int world, const int *devices, ort_comm **out);
+void ort_comm_destroy(ort_comm *comm);
+/* the collective: every rank passes its packed blocks (device pointer, same width/height/world as rendered with);
+   rank 0 also passes the full frame to assemble (device pointer, width*height*3 floats), others NULL.  Enqueued on
+   hip_stream of the communicator's device; returns without waiting. */
+int ort_gather_framebuffer(ort_comm *comm, const void *d_packed, void *d_full_rgb, int32_t width, int32_t height, void *hip_stream);
+/* the same for ort_comm_create_local's communicators, all ranks in one call (streams may be NULL) */
+int ort_gather_framebuffer_local(ort_comm **comms, int world, const void *const *d_packed, void *d_full_rgb_rank0, int32_t width,
+                                 int32_t height, void *const *hip_streams);
 
 /* ---- diagnostics: per-function evaluation ON THE DEVICE (parity tests) -----------------
  * records: count x {u32 op; f32 in[24]}; out: count x f32[8].  Ops (reference file:line):

@@ -19,6 +19,8 @@ OK, ERR_INVALID, ERR_IO, ERR_PARSE, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR
 POLICY_TILE32, POLICY_WHOLE, POLICY_PIXEL, POLICY_CHUNK = range(4)
 POLICIES = {"tile32": POLICY_TILE32, "whole": POLICY_WHOLE, "pixel": POLICY_PIXEL, "chunk": POLICY_CHUNK}
 RENDER_COUNTERS = 1
+RENDER_PACKED = 2
+COMM_ID_BYTES = 128
 
 
 class OrtError(RuntimeError):
@@ -99,7 +101,10 @@ EXPORTS = [
     "ort_scene_get_boxes", "ort_scene_get_cylinders", "ort_scene_get_lights", "ort_scene_get_mesh",
     "ort_scene_get_camera", "ort_scene_commit", "ort_scene_get_tree_info", "ort_device_count", "ort_scene_upload",
     "ort_tiled_raytrace", "ort_tiled_raytrace_batch", "ort_render_image", "ort_render_image_device",
-    "ort_render_workspace_bytes", "ort_unit_eval_device", "ort_rgbe", "ort_write_hdr"]
+    "ort_render_workspace_bytes", "ort_unit_eval_device", "ort_rgbe", "ort_write_hdr",
+    "ort_shard_block_count", "ort_pack_blocks_host", "ort_unpack_blocks_host", "ort_unpack_blocks_device",
+    "ort_comm_unique_id", "ort_comm_create", "ort_comm_create_local", "ort_comm_destroy", "ort_gather_framebuffer",
+    "ort_gather_framebuffer_local"]
 
 _lib = None
 
@@ -144,6 +149,18 @@ def lib():
         L.ort_rgbe.restype = C.c_uint32
         L.ort_rgbe.argtypes = [C.c_float, C.c_float, C.c_float]
         L.ort_write_hdr.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32]
+        L.ort_shard_block_count.argtypes = [C.c_int32, C.c_int32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
+        L.ort_pack_blocks_host.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.ort_unpack_blocks_host.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.ort_unpack_blocks_device.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+        L.ort_comm_unique_id.argtypes = [C.c_void_p]
+        L.ort_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.ort_comm_create_local.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_void_p)]
+        L.ort_comm_destroy.argtypes = [C.c_void_p]
+        L.ort_comm_destroy.restype = None
+        L.ort_gather_framebuffer.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+        L.ort_gather_framebuffer_local.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p), C.c_void_p, C.c_int32,
+                                                   C.c_int32, C.POINTER(C.c_void_p)]
         _lib = L
     return _lib
 
@@ -284,13 +301,13 @@ class Scene:
 
     # -- render ---------------------------------------------------------------------------
     @staticmethod
-    def params(width, height, spp, seed, policy="chunk", chunk=0, rect=None, rr=0.8, counters=False, shard=(0, 1)):
+    def params(width, height, spp, seed, policy="chunk", chunk=0, rect=None, rr=0.8, counters=False, shard=(0, 1), packed=False):
         x0, y0, x1, y1 = rect if rect else (0, 0, width, height)
         pol = POLICIES[policy] if isinstance(policy, str) else policy
         if pol == POLICY_CHUNK and not chunk:
             chunk = spp
         return RenderParams(width, height, x0, y0, x1, y1, pol, seed & 0xFFFFFFFF, spp, chunk, rr,
-                            RENDER_COUNTERS if counters else 0, shard[0], shard[1])
+                            (RENDER_COUNTERS if counters else 0) | (RENDER_PACKED if packed else 0), shard[0], shard[1])
 
     def render(self, width, height, spp, seed, policy="chunk", chunk=0, rect=None, rr=0.8, counters=False,
                shard=(0, 1), out=None):
@@ -352,3 +369,67 @@ def workspace_bytes(params):
     n = C.c_uint64(0)
     _check(lib().ort_render_workspace_bytes(C.byref(params), C.byref(n)))
     return n.value
+
+
+# ---- multi-GPU: block sharding and the one collective (ort_comm.cpp) -----------------------------
+def shard_block_count(width, height, index, count):
+    n = C.c_uint64(0)
+    _check(lib().ort_shard_block_count(width, height, index, count, C.byref(n)))
+    return n.value
+
+
+def pack_blocks_host(image, index, count):
+    """[H, W, 3] float32 -> this shard's packed blocks [n_blocks, 64, 3] (CPU)."""
+    image = np.ascontiguousarray(image, dtype="<f4")
+    h, w = image.shape[:2]
+    out = np.zeros((shard_block_count(w, h, index, count), 64, 3), "<f4")
+    _check(lib().ort_pack_blocks_host(image.ctypes.data, w, h, index, count, out.ctypes.data))
+    return out
+
+
+def unpack_blocks_host(packed, width, height, index, count, out=None):
+    packed = np.ascontiguousarray(packed, dtype="<f4")
+    if out is None:
+        out = np.zeros((height, width, 3), "<f4")
+    _check(lib().ort_unpack_blocks_host(packed.ctypes.data, width, height, index, count, out.ctypes.data))
+    return out
+
+
+def unpack_blocks_device(d_packed_ptr, width, height, index, count, d_full_ptr, stream=None):
+    _check(lib().ort_unpack_blocks_device(C.c_void_p(d_packed_ptr), width, height, index, count, C.c_void_p(d_full_ptr),
+                                          C.c_void_p(stream) if stream else None))
+
+
+class Comm:
+    """One rank's handle on the gather (RCCL underneath for world > 1, loaded on first use)."""
+
+    def __init__(self, handle):
+        self.handle = handle
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_ubyte * COMM_ID_BYTES)()
+        _check(lib().ort_comm_unique_id(buf))
+        return bytes(buf)
+
+    @classmethod
+    def create(cls, unique_id, rank, world, device):
+        h = C.c_void_p()
+        buf = (C.c_ubyte * COMM_ID_BYTES).from_buffer_copy(unique_id) if unique_id else None
+        _check(lib().ort_comm_create(buf, rank, world, device, C.byref(h)))
+        return cls(h.value)
+
+    def gather(self, d_packed_ptr, d_full_ptr, width, height, stream=None):
+        _check(lib().ort_gather_framebuffer(self.handle, C.c_void_p(d_packed_ptr), C.c_void_p(d_full_ptr) if d_full_ptr else None,
+                                            width, height, C.c_void_p(stream) if stream else None))
+
+    def close(self):
+        if self.handle:
+            lib().ort_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

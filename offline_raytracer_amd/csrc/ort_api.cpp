@@ -7,6 +7,7 @@
 #include <math.h>
 #include <string.h>
 
+#include <exception>
 #include <new>
 #include <string>
 #include <vector>
@@ -48,6 +49,12 @@ int check_params(const ort_scene *scene, const ort_render_params *p) {
     if (p->shard_count > 1 && p->shard_index >= p->shard_count) return fail(ORT_ERR_INVALID, "shard index out of range");
     if (p->shard_count > 1 && (p->policy == ORT_POLICY_TILE32 || p->policy == ORT_POLICY_WHOLE))
         return fail(ORT_ERR_UNSUPPORTED, "sharding needs a per-pixel seeding policy (PIXEL or CHUNK)");
+    if (p->flags & ORT_RENDER_PACKED) {
+        if (p->policy == ORT_POLICY_TILE32 || p->policy == ORT_POLICY_WHOLE)
+            return fail(ORT_ERR_UNSUPPORTED, "a packed framebuffer needs a per-pixel seeding policy (PIXEL or CHUNK)");
+        if (p->x0 != 0 || p->y0 != 0 || p->x1 != p->width || p->y1 != p->height)
+            return fail(ORT_ERR_INVALID, "a packed framebuffer covers the whole image: the rect must be the full frame");
+    }
     if (!scene->tree.built) return fail(ORT_ERR_STATE, "ort_scene_commit has not been called");
     if (!scene->dev) return fail(ORT_ERR_NO_DEVICE, "scene is not resident on a HIP device: call ort_scene_upload (no CPU fallback)");
     return ORT_OK;
@@ -102,12 +109,28 @@ int copy_out(const std::vector<T> &v, T *out, uint32_t cap) {
 
 } // namespace
 
+
+/* No exception crosses the C boundary: an allocation failure on hostile input (or anything else the C++ side
+   throws) becomes an error code with a message instead of std::terminate under the caller's feet. */
+template <typename F>
+int guarded(F f) {
+    try {
+        return f();
+    } catch (const std::bad_alloc &) {
+        return fail(ORT_ERR_INVALID, "out of memory");
+    } catch (const std::exception &e) {
+        return fail(ORT_ERR_INVALID, std::string("internal error: ") + e.what());
+    } catch (...) {
+        return fail(ORT_ERR_INVALID, "internal error");
+    }
+}
+
 extern "C" {
 
 const char *ort_last_error(void) { return g_error.c_str(); }
-int ort_abi_version(void) { return ORT_ABI_VERSION; }
+static int ort_abi_version_impl(void) { return ORT_ABI_VERSION; }
 
-int ort_scene_parse_scn(const char *text, size_t size, const char *base_dir, ort_scene **out) {
+static int ort_scene_parse_scn_impl(const char *text, size_t size, const char *base_dir, ort_scene **out) {
     if (!text || !out) return fail(ORT_ERR_INVALID, "null argument");
     *out = nullptr;
     ort_scene *s = new (std::nothrow) ort_scene();
@@ -123,14 +146,14 @@ int ort_scene_parse_scn(const char *text, size_t size, const char *base_dir, ort
     return ORT_OK;
 }
 
-int ort_scene_load_scn(const char *scn_path, const char *base_dir, ort_scene **out) {
+static int ort_scene_load_scn_impl(const char *scn_path, const char *base_dir, ort_scene **out) {
     if (!scn_path || !out) return fail(ORT_ERR_INVALID, "null argument");
     std::vector<char> text;
     if (ort::read_file(scn_path, &text) != ORT_OK) return fail(ORT_ERR_IO, std::string("cannot read ") + scn_path);
-    return ort_scene_parse_scn(text.data(), text.size(), base_dir, out);
+    return ort_scene_parse_scn_impl(text.data(), text.size(), base_dir, out);
 }
 
-int ort_scene_create(const ort_scene_desc *d, ort_scene **out) {
+static int ort_scene_create_impl(const ort_scene_desc *d, ort_scene **out) {
     if (!d || !out) return fail(ORT_ERR_INVALID, "null argument");
     *out = nullptr;
     if (d->material_count == 0) return fail(ORT_ERR_INVALID, "material 0 (the reserved no-hit material) is required");
@@ -184,7 +207,7 @@ void ort_scene_destroy(ort_scene *scene) {
     delete scene;
 }
 
-int ort_scene_get_info(const ort_scene *s, ort_scene_info *out) {
+static int ort_scene_get_info_impl(const ort_scene *s, ort_scene_info *out) {
     if (!s || !out) return fail(ORT_ERR_INVALID, "null argument");
     memset(out, 0, sizeof(*out));
     out->material_count = (uint32_t)s->materials.size();
@@ -203,13 +226,13 @@ int ort_scene_get_info(const ort_scene *s, ort_scene_info *out) {
     return ORT_OK;
 }
 
-int ort_scene_get_materials(const ort_scene *s, ort_material *out, uint32_t cap) { return s ? copy_out(s->materials, out, cap) : fail(ORT_ERR_INVALID, "null scene"); }
-int ort_scene_get_spheres(const ort_scene *s, ort_sphere *out, uint32_t cap) { return s ? copy_out(s->spheres, out, cap) : fail(ORT_ERR_INVALID, "null scene"); }
-int ort_scene_get_boxes(const ort_scene *s, ort_box *out, uint32_t cap) { return s ? copy_out(s->boxes, out, cap) : fail(ORT_ERR_INVALID, "null scene"); }
-int ort_scene_get_cylinders(const ort_scene *s, ort_cylinder *out, uint32_t cap) { return s ? copy_out(s->cylinders, out, cap) : fail(ORT_ERR_INVALID, "null scene"); }
-int ort_scene_get_lights(const ort_scene *s, ort_light *out, uint32_t cap) { return s ? copy_out(s->lights, out, cap) : fail(ORT_ERR_INVALID, "null scene"); }
+static int ort_scene_get_materials_impl(const ort_scene *s, ort_material *out, uint32_t cap) { return s ? copy_out(s->materials, out, cap) : fail(ORT_ERR_INVALID, "null scene"); }
+static int ort_scene_get_spheres_impl(const ort_scene *s, ort_sphere *out, uint32_t cap) { return s ? copy_out(s->spheres, out, cap) : fail(ORT_ERR_INVALID, "null scene"); }
+static int ort_scene_get_boxes_impl(const ort_scene *s, ort_box *out, uint32_t cap) { return s ? copy_out(s->boxes, out, cap) : fail(ORT_ERR_INVALID, "null scene"); }
+static int ort_scene_get_cylinders_impl(const ort_scene *s, ort_cylinder *out, uint32_t cap) { return s ? copy_out(s->cylinders, out, cap) : fail(ORT_ERR_INVALID, "null scene"); }
+static int ort_scene_get_lights_impl(const ort_scene *s, ort_light *out, uint32_t cap) { return s ? copy_out(s->lights, out, cap) : fail(ORT_ERR_INVALID, "null scene"); }
 
-int ort_scene_get_mesh(const ort_scene *s, uint32_t i, ort_mesh *out) {
+static int ort_scene_get_mesh_impl(const ort_scene *s, uint32_t i, ort_mesh *out) {
     if (!s || !out) return fail(ORT_ERR_INVALID, "null argument");
     if (i >= s->meshes.size()) return fail(ORT_ERR_INVALID, "mesh index out of range");
     const ort::HostMesh &m = s->meshes[i];
@@ -223,13 +246,13 @@ int ort_scene_get_mesh(const ort_scene *s, uint32_t i, ort_mesh *out) {
     return ORT_OK;
 }
 
-int ort_scene_get_camera(const ort_scene *s, int32_t width, int32_t height, ort_camera *out) {
+static int ort_scene_get_camera_impl(const ort_scene *s, int32_t width, int32_t height, ort_camera *out) {
     if (!s || !out || width <= 0 || height <= 0) return fail(ORT_ERR_INVALID, "bad argument");
     ort::camera_basis(*s, width, height, out);
     return ORT_OK;
 }
 
-int ort_scene_commit(ort_scene *s) {
+static int ort_scene_commit_impl(ort_scene *s) {
     if (!s) return fail(ORT_ERR_INVALID, "null scene");
     std::string err;
     int rc = ort::build_tree(s, &err);
@@ -237,7 +260,7 @@ int ort_scene_commit(ort_scene *s) {
     return rc == ORT_OK ? ORT_OK : fail(rc, err);
 }
 
-int ort_scene_get_tree_info(const ort_scene *s, ort_tree_info *out) {
+static int ort_scene_get_tree_info_impl(const ort_scene *s, ort_tree_info *out) {
     if (!s || !out) return fail(ORT_ERR_INVALID, "null argument");
     if (!s->tree.built) return fail(ORT_ERR_STATE, "ort_scene_commit has not been called");
     const ort::Tree &t = s->tree;
@@ -260,14 +283,14 @@ int ort_scene_get_tree_info(const ort_scene *s, ort_tree_info *out) {
     return ORT_OK;
 }
 
-int ort_device_count(int *count) {
+static int ort_device_count_impl(int *count) {
     if (!count) return fail(ORT_ERR_INVALID, "null argument");
     std::string err;
     int rc = ort::device_count(count, &err);
     return rc == ORT_OK ? ORT_OK : fail(rc, err);
 }
 
-int ort_scene_upload(ort_scene *s, int device) {
+static int ort_scene_upload_impl(ort_scene *s, int device) {
     if (!s) return fail(ORT_ERR_INVALID, "null scene");
     if (!s->tree.built) return fail(ORT_ERR_STATE, "ort_scene_commit has not been called");
     std::string err;
@@ -275,7 +298,7 @@ int ort_scene_upload(ort_scene *s, int device) {
     return rc == ORT_OK ? ORT_OK : fail(rc, err);
 }
 
-int ort_tiled_raytrace_batch(ort_scene *s, float *out_rgb, int32_t width, int32_t height, const ort_tile_job *jobs,
+static int ort_tiled_raytrace_batch_impl(ort_scene *s, float *out_rgb, int32_t width, int32_t height, const ort_tile_job *jobs,
                              uint32_t job_count, float rr, uint32_t *final_states, ort_stats *stats) {
     if (!s || !out_rgb || (!jobs && job_count)) return fail(ORT_ERR_INVALID, "null argument");
     ort_render_params p{};
@@ -297,30 +320,30 @@ int ort_tiled_raytrace_batch(ort_scene *s, float *out_rgb, int32_t width, int32_
     return rc == ORT_OK ? ORT_OK : fail(rc, err);
 }
 
-int ort_tiled_raytrace(ort_scene *s, float *out_rgb, int32_t width, int32_t height, int32_t x0, int32_t y0, int32_t x1,
+static int ort_tiled_raytrace_impl(ort_scene *s, float *out_rgb, int32_t width, int32_t height, int32_t x0, int32_t y0, int32_t x1,
                        int32_t y1, uint32_t *rng_state, uint32_t spp, float rr, uint64_t *shape_tests) {
     if (!rng_state) return fail(ORT_ERR_INVALID, "null rng_state");
     ort_tile_job j{x0, y0, x1, y1, *rng_state, spp};
     uint32_t final_state = *rng_state;
     ort_stats st{};
-    int rc = ort_tiled_raytrace_batch(s, out_rgb, width, height, &j, 1, rr, &final_state, &st);
+    int rc = ort_tiled_raytrace_batch_impl(s, out_rgb, width, height, &j, 1, rr, &final_state, &st);
     if (rc != ORT_OK) return rc;
     *rng_state = final_state;
     if (shape_tests) *shape_tests = st.tri_tests + st.analytic_tests;
     return ORT_OK;
 }
 
-int ort_render_image(ort_scene *s, const ort_render_params *p, float *out_rgb, ort_stats *stats) {
+static int ort_render_image_impl(ort_scene *s, const ort_render_params *p, float *out_rgb, ort_stats *stats) {
     if (!out_rgb) return fail(ORT_ERR_INVALID, "null framebuffer");
     return render_common(s, p, nullptr, out_rgb, nullptr, stats);
 }
 
-int ort_render_image_device(ort_scene *s, const ort_render_params *p, void *d_out_rgb, void *hip_stream, ort_stats *stats) {
+static int ort_render_image_device_impl(ort_scene *s, const ort_render_params *p, void *d_out_rgb, void *hip_stream, ort_stats *stats) {
     if (!d_out_rgb) return fail(ORT_ERR_INVALID, "null device framebuffer");
     return render_common(s, p, d_out_rgb, nullptr, hip_stream, stats);
 }
 
-int ort_unit_eval_device(int device, const void *records, uint32_t count, float *out) {
+static int ort_unit_eval_device_impl(int device, const void *records, uint32_t count, float *out) {
     if ((!records || !out) && count) return fail(ORT_ERR_INVALID, "null argument");
     /* op 4 (cylinder): the kernel consumes the host-precomputed frame; fill it in a copy */
     std::vector<unsigned char> copy((const unsigned char *)records, (const unsigned char *)records + (size_t)count * 100u);
@@ -339,10 +362,107 @@ int ort_unit_eval_device(int device, const void *records, uint32_t count, float 
     return rc == ORT_OK ? ORT_OK : fail(rc, err);
 }
 
-int ort_render_workspace_bytes(const ort_render_params *p, uint64_t *bytes) {
+static int ort_render_workspace_bytes_impl(const ort_render_params *p, uint64_t *bytes) {
     if (!p || !bytes) return fail(ORT_ERR_INVALID, "null argument");
     *bytes = ort::render_workspace_bytes(p);
     return ORT_OK;
 }
+
+
+/* ---- multi-GPU (ort_comm.cpp) ---- */
+static int ort_shard_block_count_impl(int32_t width, int32_t height, uint32_t shard_index, uint32_t shard_count, uint64_t *blocks) {
+    if (!blocks || width <= 0 || height <= 0 || (shard_count > 1 && shard_index >= shard_count)) return fail(ORT_ERR_INVALID, "bad argument");
+    *blocks = ort::comm_shard_blocks(width, height, shard_count > 1 ? shard_index : 0, shard_count > 1 ? shard_count : 1);
+    return ORT_OK;
+}
+static int check_shard(const void *a, const void *b, int32_t w, int32_t h, uint32_t index, uint32_t count) {
+    if (!a || !b || w <= 0 || h <= 0 || count == 0 || index >= count) return fail(ORT_ERR_INVALID, "bad argument");
+    return ORT_OK;
+}
+static int ort_pack_blocks_host_impl(const float *full_rgb, int32_t width, int32_t height, uint32_t shard_index, uint32_t shard_count, float *packed) {
+    int rc = check_shard(full_rgb, packed, width, height, shard_index, shard_count);
+    if (rc == ORT_OK) ort::pack_blocks_host(full_rgb, width, height, shard_index, shard_count, packed);
+    return rc;
+}
+static int ort_unpack_blocks_host_impl(const float *packed, int32_t width, int32_t height, uint32_t shard_index, uint32_t shard_count, float *full_rgb) {
+    int rc = check_shard(full_rgb, packed, width, height, shard_index, shard_count);
+    if (rc == ORT_OK) ort::unpack_blocks_host(packed, width, height, shard_index, shard_count, full_rgb);
+    return rc;
+}
+static int ort_unpack_blocks_device_impl(const void *d_packed, int32_t width, int32_t height, uint32_t shard_index, uint32_t shard_count,
+                                         void *d_full_rgb, void *hip_stream) {
+    int rc = check_shard(d_full_rgb, d_packed, width, height, shard_index, shard_count);
+    if (rc != ORT_OK) return rc;
+    std::string err;
+    rc = ort::unpack_blocks_device(d_packed, width, height, shard_index, shard_count, d_full_rgb, hip_stream, &err);
+    return rc == ORT_OK ? ORT_OK : fail(rc, err);
+}
+static int ort_comm_unique_id_impl(void *id) {
+    if (!id) return fail(ORT_ERR_INVALID, "null argument");
+    std::string err;
+    int rc = ort::comm_unique_id(id, &err);
+    return rc == ORT_OK ? ORT_OK : fail(rc, err);
+}
+static int ort_comm_create_impl(const void *id, int rank, int world, int device, ort_comm **out) {
+    if (!out) return fail(ORT_ERR_INVALID, "null argument");
+    std::string err;
+    ort::Comm *c = nullptr;
+    int rc = ort::comm_create(id, rank, world, device, &c, &err);
+    *out = (ort_comm *)c;
+    return rc == ORT_OK ? ORT_OK : fail(rc, err);
+}
+static int ort_comm_create_local_impl(int world, const int *devices, ort_comm **out) {
+    if (!out || world < 1) return fail(ORT_ERR_INVALID, "bad argument");
+    std::string err;
+    int rc = ort::comm_create_local(world, devices, (ort::Comm **)out, &err);
+    return rc == ORT_OK ? ORT_OK : fail(rc, err);
+}
+static int ort_gather_framebuffer_impl(ort_comm *comm, const void *d_packed, void *d_full_rgb, int32_t width, int32_t height, void *hip_stream) {
+    if (!comm || !d_packed || width <= 0 || height <= 0) return fail(ORT_ERR_INVALID, "bad argument");
+    std::string err;
+    int rc = ort::gather_framebuffer((ort::Comm *)comm, d_packed, d_full_rgb, width, height, hip_stream, &err);
+    return rc == ORT_OK ? ORT_OK : fail(rc, err);
+}
+static int ort_gather_framebuffer_local_impl(ort_comm **comms, int world, const void *const *d_packed, void *d_full_rgb_rank0, int32_t width,
+                                             int32_t height, void *const *hip_streams) {
+    if (!comms || !d_packed || !d_full_rgb_rank0 || world < 1 || width <= 0 || height <= 0) return fail(ORT_ERR_INVALID, "bad argument");
+    std::string err;
+    int rc = ort::gather_framebuffer_local((ort::Comm **)comms, world, d_packed, d_full_rgb_rank0, width, height, hip_streams, &err);
+    return rc == ORT_OK ? ORT_OK : fail(rc, err);
+}
+
+/* ---- the exported entry points: every one behind guarded() ---- */
+int ort_abi_version(void) { return guarded([&]() { return ort_abi_version_impl(); }); }
+int ort_scene_parse_scn(const char *text, size_t size, const char *base_dir, ort_scene **out) { return guarded([&]() { return ort_scene_parse_scn_impl(text, size, base_dir, out); }); }
+int ort_scene_load_scn(const char *scn_path, const char *base_dir, ort_scene **out) { return guarded([&]() { return ort_scene_load_scn_impl(scn_path, base_dir, out); }); }
+int ort_scene_create(const ort_scene_desc *d, ort_scene **out) { return guarded([&]() { return ort_scene_create_impl(d, out); }); }
+int ort_scene_get_info(const ort_scene *s, ort_scene_info *out) { return guarded([&]() { return ort_scene_get_info_impl(s, out); }); }
+int ort_scene_get_materials(const ort_scene *s, ort_material *out, uint32_t cap) { return guarded([&]() { return ort_scene_get_materials_impl(s, out, cap); }); }
+int ort_scene_get_spheres(const ort_scene *s, ort_sphere *out, uint32_t cap) { return guarded([&]() { return ort_scene_get_spheres_impl(s, out, cap); }); }
+int ort_scene_get_boxes(const ort_scene *s, ort_box *out, uint32_t cap) { return guarded([&]() { return ort_scene_get_boxes_impl(s, out, cap); }); }
+int ort_scene_get_cylinders(const ort_scene *s, ort_cylinder *out, uint32_t cap) { return guarded([&]() { return ort_scene_get_cylinders_impl(s, out, cap); }); }
+int ort_scene_get_lights(const ort_scene *s, ort_light *out, uint32_t cap) { return guarded([&]() { return ort_scene_get_lights_impl(s, out, cap); }); }
+int ort_scene_get_mesh(const ort_scene *s, uint32_t i, ort_mesh *out) { return guarded([&]() { return ort_scene_get_mesh_impl(s, i, out); }); }
+int ort_scene_get_camera(const ort_scene *s, int32_t width, int32_t height, ort_camera *out) { return guarded([&]() { return ort_scene_get_camera_impl(s, width, height, out); }); }
+int ort_scene_commit(ort_scene *s) { return guarded([&]() { return ort_scene_commit_impl(s); }); }
+int ort_scene_get_tree_info(const ort_scene *s, ort_tree_info *out) { return guarded([&]() { return ort_scene_get_tree_info_impl(s, out); }); }
+int ort_device_count(int *count) { return guarded([&]() { return ort_device_count_impl(count); }); }
+int ort_scene_upload(ort_scene *s, int device) { return guarded([&]() { return ort_scene_upload_impl(s, device); }); }
+int ort_tiled_raytrace_batch(ort_scene *s, float *out_rgb, int32_t width, int32_t height, const ort_tile_job *jobs, uint32_t job_count, float rr, uint32_t *final_states, ort_stats *stats) { return guarded([&]() { return ort_tiled_raytrace_batch_impl(s, out_rgb, width, height, jobs, job_count, rr, final_states, stats); }); }
+int ort_tiled_raytrace(ort_scene *s, float *out_rgb, int32_t width, int32_t height, int32_t x0, int32_t y0, int32_t x1, int32_t y1, uint32_t *rng_state, uint32_t spp, float rr, uint64_t *shape_tests) { return guarded([&]() { return ort_tiled_raytrace_impl(s, out_rgb, width, height, x0, y0, x1, y1, rng_state, spp, rr, shape_tests); }); }
+int ort_render_image(ort_scene *s, const ort_render_params *p, float *out_rgb, ort_stats *stats) { return guarded([&]() { return ort_render_image_impl(s, p, out_rgb, stats); }); }
+int ort_render_image_device(ort_scene *s, const ort_render_params *p, void *d_out_rgb, void *hip_stream, ort_stats *stats) { return guarded([&]() { return ort_render_image_device_impl(s, p, d_out_rgb, hip_stream, stats); }); }
+int ort_unit_eval_device(int device, const void *records, uint32_t count, float *out) { return guarded([&]() { return ort_unit_eval_device_impl(device, records, count, out); }); }
+int ort_render_workspace_bytes(const ort_render_params *p, uint64_t *bytes) { return guarded([&]() { return ort_render_workspace_bytes_impl(p, bytes); }); }
+int ort_shard_block_count(int32_t width, int32_t height, uint32_t shard_index, uint32_t shard_count, uint64_t *blocks) { return guarded([&]() { return ort_shard_block_count_impl(width, height, shard_index, shard_count, blocks); }); }
+int ort_pack_blocks_host(const float *full_rgb, int32_t width, int32_t height, uint32_t shard_index, uint32_t shard_count, float *packed) { return guarded([&]() { return ort_pack_blocks_host_impl(full_rgb, width, height, shard_index, shard_count, packed); }); }
+int ort_unpack_blocks_host(const float *packed, int32_t width, int32_t height, uint32_t shard_index, uint32_t shard_count, float *full_rgb) { return guarded([&]() { return ort_unpack_blocks_host_impl(packed, width, height, shard_index, shard_count, full_rgb); }); }
+int ort_unpack_blocks_device(const void *d_packed, int32_t width, int32_t height, uint32_t shard_index, uint32_t shard_count, void *d_full_rgb, void *hip_stream) { return guarded([&]() { return ort_unpack_blocks_device_impl(d_packed, width, height, shard_index, shard_count, d_full_rgb, hip_stream); }); }
+int ort_comm_unique_id(void *id) { return guarded([&]() { return ort_comm_unique_id_impl(id); }); }
+int ort_comm_create(const void *id, int rank, int world, int device, ort_comm **out) { return guarded([&]() { return ort_comm_create_impl(id, rank, world, device, out); }); }
+int ort_comm_create_local(int world, const int *devices, ort_comm **out) { return guarded([&]() { return ort_comm_create_local_impl(world, devices, out); }); }
+int ort_gather_framebuffer(ort_comm *comm, const void *d_packed, void *d_full_rgb, int32_t width, int32_t height, void *hip_stream) { return guarded([&]() { return ort_gather_framebuffer_impl(comm, d_packed, d_full_rgb, width, height, hip_stream); }); }
+int ort_gather_framebuffer_local(ort_comm **comms, int world, const void *const *d_packed, void *d_full_rgb_rank0, int32_t width, int32_t height, void *const *hip_streams) { return guarded([&]() { return ort_gather_framebuffer_local_impl(comms, world, d_packed, d_full_rgb_rank0, width, height, hip_streams); }); }
+void ort_comm_destroy(ort_comm *comm) { try { ort::comm_destroy((ort::Comm *)comm); } catch (...) {} }
 
 } // extern "C"

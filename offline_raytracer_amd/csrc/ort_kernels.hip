@@ -52,7 +52,8 @@ constexpr int kTabSphereMat = kTabBoxMat + kTabPrimMatCap / 4;
 constexpr int kTabCylMat = kTabSphereMat + kTabPrimMatCap / 4;
 constexpr int kTabMats = kTabCylMat + kTabPrimMatCap / 4; /* DevMaterial records, 5 each */
 constexpr int kTabMatCap = 48;
-constexpr int kTabF4 = kTabMats + 5 * kTabMatCap; /* 375 float4 = 6000 B */
+constexpr int kTabTreelet = kTabMats + 5 * kTabMatCap; /* nodes [0, kTreeletNodes) of the fast tree, breadth-first top (ort_tree.cpp) */
+constexpr int kTabF4 = kTabTreelet + 4 * (int)kTreeletNodes; /* 503 float4 = 8048 B */
 enum : uint32_t { TAB_PRO = 1u, TAB_LIGHTS = 2u, TAB_PRIM_MATS = 4u, TAB_MATS = 8u };
 
 struct SceneView {
@@ -103,8 +104,9 @@ struct RenderView {
                           fewer lanes than this are still walking interior nodes */
     uint32_t shard_index, shard_count, blocks_w, my_blocks;
     uint32_t block_x0, block_y0; /* unsharded renders enumerate only the 8x8 blocks that touch the rect */
-    float *out;      /* W*H*3 */
-    float *partial;  /* nchunks * W*H*3 (CHUNK) */
+    float *out;      /* W*H*3, or (packed_out) this shard's blocks: my_blocks * 64 * 3 */
+    float *partial;  /* CHUNK: nchunks planes of this shard's blocks, my_blocks * 64 * 3 floats each */
+    int packed_out;  /* ORT_RENDER_PACKED: out holds only this shard's 8x8 blocks, [local block][pixel in block][rgb] */
     unsigned long long *next_job;
     unsigned long long *counters; /* paths rays node_tests tri_tests analytic_tests fallback_rays */
     /* ray exchange (pt_lane_x): every wave owns two LIFO stashes in HBM, L for parked paths whose ray is still
@@ -159,6 +161,8 @@ struct DeviceScene {
     void *states = nullptr;
     size_t states_bytes = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_done = nullptr; /* end of the last render enqueued on this scene */
+    bool inflight = false;        /* that render was returned from without waiting (device form, stats == NULL) */
     int cu_count = 0;
     void *stash = nullptr; /* ray exchange: the waves' stashes */
     size_t stash_bytes = 0;
@@ -510,8 +514,18 @@ struct HitState {
     float runner_t = 0; /* nearest hit other than the winner, exact below best_t * 1.0002 (kCullSlack) */
 };
 
-ORT_D float *job_plane(const RenderView &rv, uint32_t plane) {
-    return (rv.mode == JOBS_CHUNK) ? rv.partial + (size_t)plane * (size_t)rv.W * (size_t)rv.H * 3u : rv.out;
+/* position of pixel (x, y) in this shard's packed block layout [local block][pixel in block]: blocks are numbered
+   row-major over the block grid and dealt round-robin, so the shard's k-th block is block shard_index + k * shard_count */
+ORT_D size_t packed_index(const RenderView &rv, uint32_t x, uint32_t y) {
+    const uint32_t blk = ((y >> 3) - rv.block_y0) * rv.blocks_w + ((x >> 3) - rv.block_x0);
+    return (size_t)((blk - rv.shard_index) / rv.shard_count) * 64u + ((y & 7u) << 3) + (x & 7u);
+}
+/* where a job writes pixel (x, y): its partial plane (CHUNK; packed, so a shard keeps 1/N of a frame per plane) or
+   the output image (full frame, or packed on request) */
+ORT_D float *pixel_ptr(const RenderView &rv, uint32_t plane, uint32_t x, uint32_t y) {
+    if (rv.mode == JOBS_CHUNK) return rv.partial + ((size_t)plane * rv.my_blocks * 64u + packed_index(rv, x, y)) * 3u;
+    if (rv.packed_out) return rv.out + packed_index(rv, x, y) * 3u;
+    return rv.out + 3u * ((size_t)y * (size_t)rv.W + (size_t)x);
 }
 
 /* traversal state of one ray on the fast tree */
@@ -677,7 +691,7 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderView &rv, const float4 *
                 /* ray.cpp:1428 */
                 V3 o = divs(P.color, (float)P.spp);
                 uint32_t px = P.pxy & 0xffffu, py = P.pxy >> 16;
-                float *p = job_plane(rv, P.jyp >> 16) + 3u * ((size_t)py * (size_t)rv.W + (size_t)px);
+                float *p = pixel_ptr(rv, P.jyp >> 16, px, py);
                 p[0] = o.x; p[1] = o.y; p[2] = o.z;
                 px++;
                 if (px == (P.jxx >> 16)) { px = P.jxx & 0xffffu; py++; }
@@ -881,9 +895,9 @@ ORT_D void begin_ray(const SceneView &sv, const float4 *tab, const PathState &P,
  * conservative; fminf/fmaxf drop the NaN of 0 * inf, i.e. that axis is ignored.
  * Returns when this lane's ray is finished, or -- refill_below > 0 -- as soon as fewer than
  * refill_below lanes of the wave are still traversing (the caller resumes later: all state is in T/h). */
-template <bool COUNTERS, int LDS_ENTRIES, int BLOCK>
+template <bool COUNTERS, int LDS_ENTRIES, int BLOCK, bool TREELET = false>
 ORT_D bool traverse(const SceneView &sv, V3 org, V3 dir, Trav &T, HitState &h, uint32_t *lds_stack, uint32_t *spill, int tid,
-                    int refill_below, int descend_below, Counters &c, Prof &pr, uint32_t excl = kNoPrim) {
+                    int refill_below, int descend_below, Counters &c, Prof &pr, uint32_t excl = kNoPrim, const float4 *tab = nullptr) {
     bool tracing = true;
     uint32_t cur = T.cur;
     int sp = T.sp;
@@ -901,8 +915,16 @@ ORT_D bool traverse(const SceneView &sv, V3 org, V3 dir, Trav &T, HitState &h, u
         if (!(cur & LEAF_BIT)) {
 #endif
             ORT_UTIL(sv, 0, true);
-            const float4 *np = sv.nodes + 4u * (cur & NODE_INDEX_MASK);
-            visit_node<COUNTERS, LDS_ENTRIES, BLOCK>(np[0], np[1], np[2], np[3], org, inv_d, h.best_t, cur, sp, lds_stack, spill, tid, c);
+            const uint32_t ni = cur & NODE_INDEX_MASK;
+            float4 na, nb, nc, nd;
+            if (TREELET && ni < kTreeletNodes) { /* the top of the tree: LDS */
+                const float4 *np = tab + kTabTreelet + 4u * ni;
+                na = np[0]; nb = np[1]; nc = np[2]; nd = np[3];
+            } else {
+                const float4 *np = sv.nodes + 4u * ni;
+                na = np[0]; nb = np[1]; nc = np[2]; nd = np[3];
+            }
+            visit_node<COUNTERS, LDS_ENTRIES, BLOCK>(na, nb, nc, nd, org, inv_d, h.best_t, cur, sp, lds_stack, spill, tid, c);
 #if ORT_TRAV_WHILEWHILE
             /* the stragglers of the descend loop would keep the rest of the wave waiting: break out
                and come back for them (their cur / sp carry over) */
@@ -1042,7 +1064,7 @@ ORT_D void pt_lane(const SceneView &sv, const RenderView &rv, const float4 *tab,
             }
         }
         if (ORT_BALLOT(P.ps != PS_DONE) == 0ull) break;
-        if (tracing) tracing = traverse<COUNTERS, kLdsStack, kBlock>(sv, P.org, P.dir, T, h, lds_stack, spill, tid, rv.refill_below, rv.descend_below, c, pr);
+        if (tracing) tracing = traverse<COUNTERS, kLdsStack, kBlock, TABS>(sv, P.org, P.dir, T, h, lds_stack, spill, tid, rv.refill_below, rv.descend_below, c, pr, kNoPrim, tab);
     }
     flush_counters(rv, c, COUNTERS);
 }
@@ -1229,7 +1251,7 @@ ORT_D void pt_lane_x(const SceneView &sv, const RenderView &rv, const float4 *ta
         /* in a traversal phase come back for more parked rays when half the lanes have finished; otherwise (and once
            L is empty) when only stragglers are left, which then park */
         const int below = (long_phase && ltop > 0u) ? (int)rv.long_refill : rv.refill_below;
-        if (tracing) tracing = traverse<COUNTERS, kLdsStack, kBlock>(sv, P.org, P.dir, T, h, lds_stack, spill, tid, below, rv.descend_below, c, pr);
+        if (tracing) tracing = traverse<COUNTERS, kLdsStack, kBlock, TABS>(sv, P.org, P.dir, T, h, lds_stack, spill, tid, below, rv.descend_below, c, pr, kNoPrim, tab);
     }
     flush_counters(rv, c, COUNTERS);
 }
@@ -1302,15 +1324,14 @@ ORT_D void combine_pixel(const RenderView &rv, unsigned long long idx) {
     int x = (int)((rv.block_x0 + blk % rv.blocks_w) * 8u + (pin & 7u));
     int y = (int)((rv.block_y0 + blk / rv.blocks_w) * 8u + (pin >> 3));
     if (x < rv.x0 || x >= rv.x1 || y < rv.y0 || y >= rv.y1) return;
-    size_t pix = (size_t)y * (size_t)rv.W + (size_t)x;
-    size_t plane = (size_t)rv.W * (size_t)rv.H * 3u;
+    const size_t plane = (size_t)rv.my_blocks * 64u * 3u; /* partial planes are packed: idx is the pixel's place in each */
     V3 acc = mk(0, 0, 0);
     for (uint32_t k = 0; k < rv.nchunks; ++k) {
-        const float *p = rv.partial + (size_t)k * plane + 3u * pix;
+        const float *p = rv.partial + (size_t)k * plane + 3u * (size_t)idx;
         acc = add(acc, mk(p[0], p[1], p[2]));
     }
     acc = divs(acc, (float)rv.nchunks);
-    float *o = rv.out + 3u * pix;
+    float *o = rv.packed_out ? rv.out + 3u * (size_t)idx : rv.out + 3u * ((size_t)y * (size_t)rv.W + (size_t)x);
     o[0] = acc.x; o[1] = acc.y; o[2] = acc.z;
 }
 
@@ -1517,6 +1538,7 @@ void device_release(Scene *scene) {
     if (d->h_active) (void)hipHostFree(d->h_active);
     if (d->ev0) (void)hipEventDestroy(d->ev0);
     if (d->ev1) (void)hipEventDestroy(d->ev1);
+    if (d->ev_done) (void)hipEventDestroy(d->ev_done);
     delete d;
     scene->dev = nullptr;
 }
@@ -1563,6 +1585,11 @@ int device_upload(Scene *scene, int device, std::string *err) {
         uint32_t *tw = (uint32_t *)tab.data();
         d->tab_flags = 0;
         if (!t.nodes.empty()) memcpy(&tab[kTabRoot], &t.nodes[0], sizeof(DevNode));
+        {
+            /* the top of the fast tree; slots beyond the tree's size are never addressed */
+            const size_t nt = t.nodes.size() < (size_t)kTreeletNodes ? t.nodes.size() : (size_t)kTreeletNodes;
+            if (nt) memcpy(&tab[kTabTreelet], t.nodes.data(), nt * sizeof(DevNode));
+        }
         if (2u * t.pro_boxes + t.pro_spheres + 4u * t.pro_cyls <= (uint32_t)kTabProCap) {
             float4 *q = &tab[kTabPro];
             if (t.pro_boxes) memcpy(q, t.boxes.data(), (size_t)t.pro_boxes * sizeof(DevBox));
@@ -1604,6 +1631,7 @@ int device_upload(Scene *scene, int device, std::string *err) {
     ORT_HIP(hipMemset(d->ctrl, 0, 128 * sizeof(unsigned long long)));
     ORT_HIP(hipEventCreate(&d->ev0));
     ORT_HIP(hipEventCreate(&d->ev1));
+    ORT_HIP(hipEventCreateWithFlags(&d->ev_done, hipEventDisableTiming));
     hipDeviceProp_t prop;
     ORT_HIP(hipGetDeviceProperties(&prop, device));
     d->cu_count = prop.multiProcessorCount;
@@ -1643,10 +1671,32 @@ int device_unit_eval(int device, const void *records, uint32_t n, float *out, st
     return ORT_OK;
 }
 
+/* the 8x8 blocks a PIXEL / CHUNK render enumerates: the whole grid in its global numbering when sharded (that is
+   what block_id % world == rank refers to), only the blocks under the rect on one GPU */
+struct BlockGrid { uint32_t blocks_w, block_x0, block_y0, my_blocks, shard_index, shard_count; };
+static BlockGrid block_grid_for(const ort_render_params *p) {
+    BlockGrid g;
+    g.shard_count = p->shard_count > 1 ? p->shard_count : 1;
+    g.shard_index = p->shard_count > 1 ? p->shard_index : 0;
+    g.blocks_w = (uint32_t)((p->width + 7) / 8);
+    uint32_t total = g.blocks_w * (uint32_t)((p->height + 7) / 8);
+    g.block_x0 = g.block_y0 = 0;
+    if (g.shard_count == 1 && p->x1 > p->x0 && p->y1 > p->y0) {
+        g.block_x0 = (uint32_t)(p->x0 / 8);
+        g.block_y0 = (uint32_t)(p->y0 / 8);
+        g.blocks_w = (uint32_t)((p->x1 + 7) / 8) - g.block_x0;
+        total = g.blocks_w * ((uint32_t)((p->y1 + 7) / 8) - g.block_y0);
+    }
+    g.my_blocks = (total > g.shard_index) ? (total - g.shard_index + g.shard_count - 1) / g.shard_count : 0;
+    return g;
+}
+
+uint64_t shard_block_count(const ort_render_params *p) { return block_grid_for(p).my_blocks; }
+
 uint64_t render_workspace_bytes(const ort_render_params *p) {
     if (p->policy != ORT_POLICY_CHUNK || p->chunk == 0) return 0;
     uint64_t nch = p->spp / p->chunk;
-    return nch * (uint64_t)p->width * (uint64_t)p->height * 12ull;
+    return nch * (uint64_t)block_grid_for(p).my_blocks * 64ull * 12ull; /* partial planes hold this shard's blocks only */
 }
 
 static int ensure(void **ptr, size_t *have, size_t need, std::string *err) {
@@ -1710,8 +1760,18 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
     if (!d) { *err = "scene is not uploaded to a device (ort_scene_upload)"; return ORT_ERR_NO_DEVICE; }
     ORT_HIP(hipSetDevice(d->device));
     hipStream_t stream = (hipStream_t)stream_v;
-    const size_t image_bytes = (size_t)p->width * (size_t)p->height * 12u;
+    const bool packed_out = (p->flags & ORT_RENDER_PACKED) != 0 && !jobs;
+    const size_t image_bytes = packed_out ? (size_t)block_grid_for(p).my_blocks * 768u : (size_t)p->width * (size_t)p->height * 12u;
     int rc;
+    /* One render at a time per scene: the job counter, the work counters, the partial planes and the stashes belong
+       to the scene.  A render that was returned from without waiting is waited for here, and its tripwire checked. */
+    if (d->inflight) {
+        ORT_HIP(hipEventSynchronize(d->ev_done));
+        d->inflight = false;
+        unsigned long long ovf = 0;
+        ORT_HIP(hipMemcpy(&ovf, d->ctrl + 7, sizeof(ovf), hipMemcpyDeviceToHost));
+        if (ovf) { *err = "the previous render on this scene overflowed a reference-order fallback queue"; return ORT_ERR_UNSUPPORTED; }
+    }
 
     float *out = (float *)d_out;
     if (!out) {
@@ -1777,26 +1837,21 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
     }
     rv.next_job = d->ctrl;
     rv.counters = d->ctrl + 1;
-    rv.shard_count = p->shard_count > 1 ? p->shard_count : 1;
-    rv.shard_index = p->shard_count > 1 ? p->shard_index : 0;
-    rv.blocks_w = (uint32_t)((p->width + 7) / 8);
-    uint32_t blocks_total = rv.blocks_w * (uint32_t)((p->height + 7) / 8);
-    rv.block_x0 = rv.block_y0 = 0;
-    if (rv.shard_count == 1 && !jobs && p->x1 > p->x0 && p->y1 > p->y0) {
-        /* one GPU: only the blocks under the rect (sharded renders keep the global numbering, which is
-           what block_id % world == rank and dist.py's packing refer to) */
-        rv.block_x0 = (uint32_t)(p->x0 / 8);
-        rv.block_y0 = (uint32_t)(p->y0 / 8);
-        rv.blocks_w = (uint32_t)((p->x1 + 7) / 8) - rv.block_x0;
-        blocks_total = rv.blocks_w * ((uint32_t)((p->y1 + 7) / 8) - rv.block_y0);
+    {
+        const BlockGrid g = block_grid_for(p);
+        rv.shard_count = g.shard_count; rv.shard_index = g.shard_index;
+        rv.blocks_w = g.blocks_w; rv.block_x0 = g.block_x0; rv.block_y0 = g.block_y0;
+        rv.my_blocks = g.my_blocks;
     }
-    rv.my_blocks = (blocks_total > rv.shard_index) ? (blocks_total - rv.shard_index + rv.shard_count - 1) / rv.shard_count : 0;
+    rv.packed_out = (p->flags & ORT_RENDER_PACKED) != 0 && !jobs;
 
     if (jobs) {
         rv.mode = JOBS_EXPLICIT;
         rv.job_count = job_count;
         if ((rc = ensure(&d->jobs, &d->jobs_bytes, (size_t)job_count * sizeof(ort_tile_job), err))) return rc;
-        ORT_HIP(hipMemcpyAsync(d->jobs, jobs, (size_t)job_count * sizeof(ort_tile_job), hipMemcpyHostToDevice, stream));
+        /* synchronous: the caller's job list may be gone when this call returns */
+        ORT_HIP(hipStreamSynchronize(stream));
+        ORT_HIP(hipMemcpy(d->jobs, jobs, (size_t)job_count * sizeof(ort_tile_job), hipMemcpyHostToDevice));
         rv.jobs = (const ort_tile_job *)d->jobs;
         if (final_states) {
             if ((rc = ensure(&d->states, &d->states_bytes, (size_t)job_count * 4u, err))) return rc;
@@ -1810,7 +1865,7 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
         rv.mode = JOBS_CHUNK;
         rv.nchunks = p->spp / p->chunk;
         rv.job_count = (unsigned long long)rv.my_blocks * 64ull * rv.nchunks;
-        size_t need = (size_t)rv.nchunks * image_bytes;
+        size_t need = (size_t)rv.nchunks * (size_t)rv.my_blocks * 64u * 12u; /* = render_workspace_bytes(p) */
         if ((rc = ensure((void **)&d->partial, &d->partial_bytes, need, err))) return rc;
         rv.partial = d->partial;
     }
@@ -1878,8 +1933,11 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
     if (final_states) ORT_HIP(hipMemcpyAsync(final_states, d->states, (size_t)job_count * 4u, hipMemcpyDeviceToHost, stream));
     /* a fallback queue overflow (cannot happen by construction; tripwire) must not go unnoticed: every synchronous form of the call checks it
        (the fire-and-forget device form, stats == NULL, cannot without a sync; bench.py asks for stats) */
+    ORT_HIP(hipEventRecord(d->ev_done, stream));
+    d->inflight = true;
     if (stats || !d_out || final_states) {
         ORT_HIP(hipStreamSynchronize(stream));
+        d->inflight = false;
         unsigned long long ovf = 0;
         ORT_HIP(hipMemcpy(&ovf, d->ctrl + 7, sizeof(ovf), hipMemcpyDeviceToHost));
         if (ovf) { *err = "reference-order fallback queue overflowed"; return ORT_ERR_UNSUPPORTED; }

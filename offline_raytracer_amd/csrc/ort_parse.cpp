@@ -204,6 +204,9 @@ int load_ply(const std::vector<char> &file, HostMesh *mesh, std::string *err) {
             if (what.type == PlyTok::Vertex) {
                 PlyToken n = next_ply_token(&c);
                 if (n.type != PlyTok::I32) { *err = "ply: vertex count is not an integer"; return ORT_ERR_PARSE; }
+                /* a vertex line is at least six bytes ("0 0 0\n"): a count the file cannot hold (or a negative one)
+                   is a malformed file, not a 50 GB allocation */
+                if (n.i < 0 || (size_t)n.i > file.size() / 6u) { *err = "ply: vertex count exceeds the file"; return ORT_ERR_PARSE; }
                 vertex_count = (uint32_t)n.i;
             } else if (what.type != PlyTok::Face) {
                 *err = "ply: unknown element";

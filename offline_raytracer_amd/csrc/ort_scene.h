@@ -43,6 +43,7 @@ constexpr uint32_t SPHERE_BELOW_BIT = 0x40000000u;
 constexpr uint32_t NODE_INDEX_MASK = 0x3fffffffu;
 constexpr uint32_t EMPTY_CHILD = 0xffffffffu; /* leaf, kind 7: never visited (box is inverted) */
 constexpr uint32_t MAX_LEAF_PRIMS = 16;
+constexpr uint32_t kTreeletNodes = 32; /* the breadth-first top of the fast tree has indices [0, 32): kept in LDS by the kernel */
 
 inline uint32_t make_leaf(uint32_t kind, uint32_t first, uint32_t count) {
     return LEAF_BIT | (kind << 28) | ((count - 1u) << 24) | (first & 0x00ffffffu);
@@ -170,11 +171,26 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
                   void *d_out, float *h_out, void *stream, uint32_t *final_states, ort_stats *stats, std::string *err);
 uint64_t render_workspace_bytes(const ort_render_params *p);
 int device_unit_eval(int device, const void *records, uint32_t n, float *out, std::string *err);
+uint64_t shard_block_count(const ort_render_params *p);
+/* ort_comm.cpp */
+struct Comm;
+uint64_t comm_shard_blocks(int32_t w, int32_t h, uint32_t index, uint32_t count);
+void pack_blocks_host(const float *full, int32_t w, int32_t h, uint32_t index, uint32_t count, float *packed);
+void unpack_blocks_host(const float *packed, int32_t w, int32_t h, uint32_t index, uint32_t count, float *full);
+int unpack_blocks_device(const void *d_packed, int32_t w, int32_t h, uint32_t index, uint32_t count, void *d_full, void *stream, std::string *err);
+int comm_unique_id(void *id, std::string *err);
+int comm_create(const void *id, int rank, int world, int device, Comm **out, std::string *err);
+int comm_create_local(int world, const int *devices, Comm **out, std::string *err);
+void comm_destroy(Comm *c);
+int gather_framebuffer(Comm *c, const void *d_packed, void *d_full, int32_t w, int32_t h, void *stream, std::string *err);
+int gather_framebuffer_local(Comm **cs, int world, const void *const *d_packed, void *d_full_root, int32_t w, int32_t h,
+                             void *const *streams, std::string *err);
 /* ort_tree.cpp: rotation_matrix_along_z(axis) rows + |axis| as the kernel receives them */
 void cylinder_frame_for(const ort_cylinder &c, float rot[9], float *len);
 
 } // namespace ort
 
 struct ort_scene : public ort::Scene {};
+struct ort_comm; /* = ort::Comm behind the C ABI */
 
 #endif

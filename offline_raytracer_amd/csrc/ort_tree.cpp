@@ -315,6 +315,38 @@ DevMaterial make_dev_material(const ort_material &m) {
 
 void cylinder_frame_for(const ort_cylinder &c, float rot[9], float *len) { cylinder_frame(c, rot, len); }
 
+/* The first kTreeletNodes interior nodes in breadth-first order get the indices [0, kTreeletNodes): the kernel keeps
+   that top of the tree in LDS (ort_kernels.hip, kTabTreelet), where most node visits happen.  Pure renumbering. */
+static void renumber_top_levels(Tree *tree, uint32_t top) {
+    const size_t n = tree->nodes.size();
+    if (n <= 2) return;
+    std::vector<uint32_t> order; /* new index -> old index */
+    std::vector<uint8_t> taken(n, 0);
+    order.push_back(0);
+    taken[0] = 1;
+    for (size_t h = 0; h < order.size() && order.size() < top; ++h) {
+        const DevNode &nd = tree->nodes[order[h]];
+        const uint32_t ch[2] = {nd.child0, nd.child1};
+        for (uint32_t c : ch) {
+            if (c & LEAF_BIT) continue;
+            const uint32_t i = c & NODE_INDEX_MASK;
+            if (i < n && !taken[i] && order.size() < top) { taken[i] = 1; order.push_back(i); }
+        }
+    }
+    for (uint32_t i = 0; i < n; ++i)
+        if (!taken[i]) order.push_back(i);
+    std::vector<uint32_t> new_of(n);
+    for (uint32_t k = 0; k < n; ++k) new_of[order[k]] = k;
+    std::vector<DevNode> out(n);
+    for (uint32_t k = 0; k < n; ++k) {
+        DevNode nd = tree->nodes[order[k]];
+        if (!(nd.child0 & LEAF_BIT)) nd.child0 = (nd.child0 & ~NODE_INDEX_MASK) | new_of[nd.child0 & NODE_INDEX_MASK];
+        if (!(nd.child1 & LEAF_BIT)) nd.child1 = (nd.child1 & ~NODE_INDEX_MASK) | new_of[nd.child1 & NODE_INDEX_MASK];
+        out[k] = nd;
+    }
+    tree->nodes.swap(out);
+}
+
 int build_tree(Scene *scene, std::string *err) {
     Tree fresh;
     scene->tree = fresh;
@@ -496,6 +528,7 @@ int build_tree(Scene *scene, std::string *err) {
         }
         tree->sah_cost = (float)(b.sah_sum / b.root_area);
     }
+    renumber_top_levels(tree, kTreeletNodes);
     tree->built = true;
     return ORT_OK;
 }
