@@ -1827,11 +1827,13 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
         if (rv.refill_below < 1) rv.refill_below = 1;
         if (rv.refill_below > 64) rv.refill_below = 64;
         e = getenv("ORT_DESCEND_BELOW");
-        /* 8 is worth +10 % while the fast tree is cache-resident (bunny room: 6 MB).  On the 1M-triangle
-           scene (86 MB, 60 % L2 hits, latency-bound) it halves the throughput of long launches -- L2 read
-           latency 270 -> 690 cycles at equal request counts, not understood (profiles/r01_tuning.md) --
-           so trees that cannot stay in the 8 x 4 MB of L2 keep the plain while-while loop */
-        rv.descend_below = e ? atoi(e) : (cache_resident ? 8 : 0);
+        /* cache-resident trees (bunny room: 6 MB): 8, worth +10 %.  Trees that leave the 8 x 4 MB of L2 (the 1M-triangle
+           scene, 86 MB): 16 -- 942 Mpaths/s against 667 with the plain while-while loop (3840x2160, 256 spp;
+           profiles/r02_tuning.md).  Round 1 had to switch the early exit off there; what collapsed was the COMBINATION
+           with the analytic prologue, which turns the register spills around the loop into a write storm that the L2
+           cannot absorb next to an 86 MB tree (255 GB written instead of 2.5, TCC_TAG_STALL x 50 000); the prologue
+           stays off for such trees (ort_tree.cpp) and each of the two alone is a gain */
+        rv.descend_below = e ? atoi(e) : (cache_resident ? 8 : 16);
         if (rv.descend_below < 0) rv.descend_below = 0;
         if (rv.descend_below > 64) rv.descend_below = 64;
     }

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import ref_io
-from conftest import GOLDEN, assert_bits_equal
+from conftest import GOLDEN, ROOT, assert_bits_equal
 
 pytestmark = pytest.mark.gpu
 
@@ -441,3 +441,33 @@ def test_cli_scn_to_hdr_end_to_end(api, oracle, gpu_scene, tmp_path):
         want = str(tmp_path / "want.hdr")
         assert oracle.lib().oracle_write_hdr(want.encode(), np.ascontiguousarray(ref).ctypes.data, w, h) == 0
         assert open(out, "rb").read() == open(want, "rb").read(), policy
+
+
+def test_determinant_threshold_scene(api, oracle, manifest, tmp_path_factory):
+    """DESIGN.md section 3's residual, constructed (tools/make_detscene.py): tiny triangles whose |e1 x e2| straddles the
+    1e-6 determinant threshold of ray.cpp:95-96 -- half the patch exists for the reference, half does not, the border is
+    decided by the last bits of det -- and a strip seen edge-on through the aperture ring, where hits exist only by
+    rounding.  The kernel must return the reference's own pixels (golden, from the compiled reference) and the
+    oracle's on more samples and other seeds."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_detscene
+    d = str(tmp_path_factory.mktemp("detscene")) + "/"
+    scn, nv, nf = make_detscene.write_scene(d)
+    meta = manifest["detscene"]
+    assert (nv, nf) == (meta["vertices"], meta["triangles"])
+    scene = api.Scene.load_scn(scn).commit().upload(0)
+    W, H = meta["width"], meta["height"]
+    z = np.load(os.path.join(GOLDEN, "renders_detscene.npz"))
+    for c in meta["cases"]:
+        x0, y0, x1, y1 = meta["windows"][c["window"]]
+        img, _ = scene.render(W, H, c["spp"], c["seed"], c["policy"], chunk=c["chunk"], rect=(x0, y0, x1, y1))
+        assert_bits_equal(img[y0:y1, x0:x1], z[c["key"]], "reference golden " + c["key"])
+    osc = oracle.OracleScene(scene.flatten(W, H))
+    for name, seed, spp, chunk in (("patchA", 1, 32, 8), ("stripB", 2, 32, 8), ("patchA", 3, 16, 16)):
+        x0, y0, x1, y1 = meta["windows"][name]
+        img, st = scene.render(W, H, spp, seed, "chunk", chunk=chunk, rect=(x0, y0, x1, y1), counters=True)
+        ref, _ = osc.render(W, H, spp, seed, "chunk", chunk=chunk, rect=(x0, y0, x1, y1), threads=16)
+        assert_bits_equal(img[y0:y1, x0:x1], ref[y0:y1, x0:x1], "oracle %s seed %d" % (name, seed))
+        assert st["tri_tests"] > 0
+    scene.close()
