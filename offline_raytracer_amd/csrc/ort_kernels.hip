@@ -56,6 +56,21 @@ constexpr int kTabTreelet = kTabMats + 5 * kTabMatCap; /* nodes [0, kTreeletNode
 constexpr int kTabF4 = kTabTreelet + 4 * (int)kTreeletNodes; /* 503 float4 = 8048 B */
 enum : uint32_t { TAB_PRO = 1u, TAB_LIGHTS = 2u, TAB_PRIM_MATS = 4u, TAB_MATS = 8u };
 
+/* The part of the scene view that only rare paths read -- the reference test order (bit-equal hit distances) and
+   the exact breadth-first fallback -- lives behind one pointer in HBM: as by-value kernel arguments these twenty
+   scalar registers were spilled to vector lanes and back all through the shading code. */
+struct SceneCold {
+    const float4 *ref_nodes;   /* reference-compatible octree: 3 per node */
+    const uint32_t *ref_recs;
+    const uint32_t *tri_order, *sphere_order, *box_order, *cyl_order; /* reference test order (ties) */
+    /* exact fallback: a pool of queues in HBM, each long enough for every node of the reference tree
+       (a ray enqueues a node at most once), taken with a try-lock for the duration of one re-cast */
+    uint32_t *bfs_pool;
+    uint32_t *bfs_locks;
+    uint32_t bfs_queue_cap, bfs_queue_count;
+    unsigned long long *fallback_counters; /* [0] rays re-cast exactly, [1] queue overflows (cannot happen: kept as a tripwire) */
+};
+
 struct SceneView {
     const float4 *tab_src;    /* kTabF4 float4, the image of the LDS tables */
     uint32_t tab_flags;
@@ -73,18 +88,10 @@ struct SceneView {
     uint32_t light_count;
     uint32_t pro_boxes, pro_spheres, pro_cyls; /* analytic prologue: every ray tests shapes [0, n) of each kind outright */
     float cam[12];            /* p, x_axis, y_axis, z_axis */
-    /* reference-compatible octree (ort_reftree.cpp): visibility chains + exact fallback */
-    const float4 *ref_nodes;   /* 3 per node */
-    const uint32_t *ref_recs;
+    /* reference-compatible octree (ort_reftree.cpp): visibility chains */
     const float4 *chain_boxes; /* 2 per chain entry */
     const uint32_t *tri_chain, *sphere_chain, *box_chain, *cyl_chain;
-    const uint32_t *tri_order, *sphere_order, *box_order, *cyl_order; /* reference test order (ties) */
-    /* exact fallback: a pool of queues in HBM, each long enough for every node of the reference tree
-       (a ray enqueues a node at most once), taken with a try-lock for the duration of one re-cast */
-    uint32_t *bfs_pool;
-    uint32_t *bfs_locks;
-    uint32_t bfs_queue_cap, bfs_queue_count;
-    unsigned long long *fallback_counters; /* [0] rays re-cast exactly, [1] queue overflows (cannot happen: kept as a tripwire) */
+    const SceneCold *cold; /* what only the rare paths read (ties, the exact fallback) */
     unsigned long long *util; /* diagnostics (ORT_DEBUG_UTIL=1, counters build): per-phase wave-iteration and active-lane sums */
     uint32_t force_fallback_mask; /* tests (ORT_DEBUG_FORCE_FALLBACK): also re-cast rays with (bits(dir.x) & mask) == 0; ~0u = off */
 };
@@ -142,6 +149,7 @@ struct DeviceScene {
     void *boxes = nullptr, *box_mat = nullptr, *cyls = nullptr, *cyl_mat = nullptr, *materials = nullptr;
     void *light_is_sphere = nullptr;
     void *tab = nullptr; /* image of the LDS tables (kTabF4 float4) */
+    void *cold = nullptr; /* SceneCold */
     uint32_t tab_flags = 0;
     uint32_t light_count = 0;
     bool diffuse_only = false; /* no surface material can enter the specular / transmission blocks */
@@ -256,8 +264,8 @@ constexpr uint32_t kNoPrim = 0xffffffffu;
 constexpr uint32_t kTraversalDone = 0xffffffffu; /* == EMPTY_CHILD: a leaf word no tree contains */
 
 ORT_D uint32_t prim_order(const SceneView &sv, uint32_t kind, uint32_t slot) {
-    return (kind == PRIM_TRI) ? sv.tri_order[slot] : (kind == PRIM_SPHERE) ? sv.sphere_order[slot]
-         : (kind == PRIM_BOX) ? sv.box_order[slot] : sv.cyl_order[slot];
+    return (kind == PRIM_TRI) ? sv.cold->tri_order[slot] : (kind == PRIM_SPHERE) ? sv.cold->sphere_order[slot]
+         : (kind == PRIM_BOX) ? sv.cold->box_order[slot] : sv.cold->cyl_order[slot];
 }
 
 /* one primitive against the ray, exactly as raycast_bvh does per record (ray.cpp:647-716):
@@ -446,22 +454,22 @@ ORT_D bool ref_raycast_bfs(const SceneView &sv, V3 org, V3 dir, V3 inv_d, uint32
     float unused = 0;
     uint32_t head = 0, tail = 0;
     bool ok = true;
-    const uint32_t cap = sv.bfs_queue_cap;
+    const uint32_t cap = sv.cold->bfs_queue_cap;
     queue[tail++] = 0;
     while (head != tail) {
         uint32_t node = queue[head++];
-        const float4 *np = sv.ref_nodes + 3u * node;
+        const float4 *np = sv.cold->ref_nodes + 3u * node;
         float4 a = np[0], b = np[1], c = np[2];
         int32_t first_child = (int32_t)om_f32_bits(a.w);
         uint32_t rec_first = om_f32_bits(b.w), rec_count = om_f32_bits(c.x);
         for (uint32_t r = 0; r < rec_count; ++r) {
-            uint32_t rec = sv.ref_recs[rec_first + r];
+            uint32_t rec = sv.cold->ref_recs[rec_first + r];
             test_prim<COUNTERS, true>(sv, rec >> 28, rec & 0x00ffffffu, org, dir, inv_d, best_t, hit_n, hit_prim, unused, unused, c_tris, c_analytic);
         }
         if (first_child >= 0) {
             for (uint32_t k = 0; k < 8u; ++k) {
                 uint32_t ci = (uint32_t)first_child + k;
-                const float4 *cp = sv.ref_nodes + 3u * ci;
+                const float4 *cp = sv.cold->ref_nodes + 3u * ci;
                 float4 ca = cp[0], cb = cp[1], cc = cp[2];
                 uint32_t flags = om_f32_bits(cc.y);
                 bool leaf_with_records = (flags & 3u) == 3u;
@@ -575,15 +583,15 @@ ORT_D void recast_exactly(const SceneView &sv, bool need, V3 org, V3 dir, V3 inv
     while (pending) {
         const int leader = ORT_FFS64(pending) - 1;
         if (ORT_LANE() == leader) {
-            ORT_COUNT(sv.fallback_counters, 1ull); /* straight to memory, no register kept across the loop */
-            uint32_t slot = ((lane_id * 2654435761u) >> 8) % sv.bfs_queue_count;
-            while (!ORT_TRY_LOCK(sv.bfs_locks + slot)) slot = (slot + 1u) % sv.bfs_queue_count;
+            ORT_COUNT(sv.cold->fallback_counters, 1ull); /* straight to memory, no register kept across the loop */
+            uint32_t slot = ((lane_id * 2654435761u) >> 8) % sv.cold->bfs_queue_count;
+            while (!ORT_TRY_LOCK(sv.cold->bfs_locks + slot)) slot = (slot + 1u) % sv.cold->bfs_queue_count;
             ORT_FENCE();
-            if (!ref_raycast_bfs<COUNTERS>(sv, org, dir, inv_d, sv.bfs_pool + (size_t)slot * sv.bfs_queue_cap, h.best_t, h.hit_n,
+            if (!ref_raycast_bfs<COUNTERS>(sv, org, dir, inv_d, sv.cold->bfs_pool + (size_t)slot * sv.cold->bfs_queue_cap, h.best_t, h.hit_n,
                                            h.hit_prim, c.nodes, c.tris, c.analytic))
-                ORT_COUNT(sv.fallback_counters + 1, 1ull);
+                ORT_COUNT(sv.cold->fallback_counters + 1, 1ull);
             ORT_FENCE();
-            ORT_UNLOCK(sv.bfs_locks + slot);
+            ORT_UNLOCK(sv.cold->bfs_locks + slot);
         }
         pending &= pending - 1ull;
     }
@@ -1529,7 +1537,7 @@ void device_release(Scene *scene) {
     if (!d) return;
     (void)hipSetDevice(d->device);
     void *ptrs[] = {d->nodes, d->tris, d->tri_mat, d->spheres, d->sphere_mat, d->boxes, d->box_mat, d->cyls, d->cyl_mat,
-                    d->materials, d->light_is_sphere, d->tab, d->ref_nodes, d->ref_recs, d->chain_boxes, d->tri_chain, d->sphere_chain,
+                    d->materials, d->light_is_sphere, d->tab, d->cold, d->ref_nodes, d->ref_recs, d->chain_boxes, d->tri_chain, d->sphere_chain,
                     d->box_chain, d->cyl_chain, d->tri_order, d->sphere_order, d->box_order, d->cyl_order, d->bfs_pool, d->bfs_locks, d->ctrl, d->partial, d->staging, d->jobs, d->states};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -1650,6 +1658,17 @@ int device_upload(Scene *scene, int device, std::string *err) {
     ORT_HIP(hipMalloc(&d->bfs_locks, (size_t)d->bfs_queue_count * sizeof(uint32_t)));
     ORT_HIP(hipMemset(d->bfs_locks, 0, (size_t)d->bfs_queue_count * sizeof(uint32_t)));
     ORT_HIP(hipHostMalloc((void **)&d->h_active, sizeof(unsigned long long)));
+    {
+        SceneCold cold{};
+        cold.ref_nodes = (const float4 *)d->ref_nodes; cold.ref_recs = (const uint32_t *)d->ref_recs;
+        cold.tri_order = (const uint32_t *)d->tri_order; cold.sphere_order = (const uint32_t *)d->sphere_order;
+        cold.box_order = (const uint32_t *)d->box_order; cold.cyl_order = (const uint32_t *)d->cyl_order;
+        cold.bfs_pool = (uint32_t *)d->bfs_pool; cold.bfs_locks = (uint32_t *)d->bfs_locks;
+        cold.bfs_queue_cap = d->bfs_queue_cap; cold.bfs_queue_count = d->bfs_queue_count;
+        cold.fallback_counters = d->ctrl + 6;
+        ORT_HIP(hipMalloc(&d->cold, sizeof(SceneCold)));
+        ORT_HIP(hipMemcpy(d->cold, &cold, sizeof(SceneCold), hipMemcpyHostToDevice));
+    }
     return ORT_OK;
 }
 
@@ -1793,19 +1812,12 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
     sv.pro_boxes = scene->tree.pro_boxes;
     sv.pro_spheres = scene->tree.pro_spheres;
     sv.pro_cyls = scene->tree.pro_cyls;
-    sv.ref_nodes = (const float4 *)d->ref_nodes; sv.ref_recs = (const uint32_t *)d->ref_recs;
     sv.chain_boxes = (const float4 *)d->chain_boxes;
     sv.tri_chain = (const uint32_t *)d->tri_chain; sv.sphere_chain = (const uint32_t *)d->sphere_chain;
     sv.box_chain = (const uint32_t *)d->box_chain; sv.cyl_chain = (const uint32_t *)d->cyl_chain;
-    sv.tri_order = (const uint32_t *)d->tri_order; sv.sphere_order = (const uint32_t *)d->sphere_order;
-    sv.box_order = (const uint32_t *)d->box_order; sv.cyl_order = (const uint32_t *)d->cyl_order;
-    sv.bfs_pool = (uint32_t *)d->bfs_pool;
-    sv.bfs_locks = (uint32_t *)d->bfs_locks;
-    sv.bfs_queue_cap = d->bfs_queue_cap;
-    sv.bfs_queue_count = d->bfs_queue_count;
     const char *ff = getenv("ORT_DEBUG_FORCE_FALLBACK");
     sv.force_fallback_mask = ff ? (uint32_t)strtoul(ff, nullptr, 0) : 0xffffffffu;
-    sv.fallback_counters = d->ctrl + 6;
+    sv.cold = (const SceneCold *)d->cold;
     const bool want_util = getenv("ORT_DEBUG_UTIL") != nullptr; /* developer diagnostics, counters build only */
     sv.util = want_util ? d->ctrl + 8 : nullptr;
     ort_camera cam;

@@ -54,9 +54,10 @@ int main(int argc, char **argv) {
     sv.light_is_sphere = lis.data(); sv.light_count = (uint32_t)lis.size();
     sv.pro_boxes = t.pro_boxes; sv.pro_spheres = t.pro_spheres; sv.pro_cyls = t.pro_cyls;
     const RefTree &rt = scene->ref;
-    sv.ref_nodes = (const float4 *)rt.nodes.data(); sv.ref_recs = rt.recs.data(); sv.chain_boxes = (const float4 *)rt.chain_boxes.data();
+    static SceneCold cold; sv.cold = &cold;
+    cold.ref_nodes = (const float4 *)rt.nodes.data(); cold.ref_recs = rt.recs.data(); sv.chain_boxes = (const float4 *)rt.chain_boxes.data();
     sv.tri_chain = rt.tri_chain.data(); sv.sphere_chain = rt.sphere_chain.data(); sv.box_chain = rt.box_chain.data(); sv.cyl_chain = rt.cyl_chain.data();
-    sv.tri_order = rt.tri_order.data(); sv.sphere_order = rt.sphere_order.data(); sv.box_order = rt.box_order.data(); sv.cyl_order = rt.cyl_order.data();
+    cold.tri_order = rt.tri_order.data(); cold.sphere_order = rt.sphere_order.data(); cold.box_order = rt.box_order.data(); cold.cyl_order = rt.cyl_order.data();
     fprintf(stderr, "ref octree: %zu nodes, %u leaves, max leaf %u, chain boxes %zu\n", rt.nodes.size(), rt.nonempty_leaves, rt.max_leaf_records, rt.chain_boxes.size() / 2);
     ort_camera cam;
     camera_basis(*scene, W, H, &cam);
@@ -70,7 +71,7 @@ int main(int argc, char **argv) {
     rv.refill_below = 12;
     rv.descend_below = getenv("SIM_DESCEND_BELOW") ? atoi(getenv("SIM_DESCEND_BELOW")) : 8;
     rv.out = out.data(); rv.next_job = ctrl; rv.counters = ctrl + 1;
-    sv.fallback_counters = ctrl + 6;
+    cold.fallback_counters = ctrl + 6;
     rv.shard_count = argc > 11 ? (uint32_t)atoi(argv[11]) : 1; rv.shard_index = argc > 11 ? (uint32_t)atoi(argv[10]) : 0;
     rv.block_x0 = rv.block_y0 = 0;
     rv.blocks_w = (uint32_t)((W + 7) / 8);
@@ -103,10 +104,10 @@ int main(int argc, char **argv) {
     auto t0 = std::chrono::steady_clock::now();
     std::vector<float> lds_focal(3 * kBlock);
     std::vector<uint32_t> bfsq(scene->ref.nodes.size() + 8), bfs_lock(1, 0u);
-    sv.bfs_pool = bfsq.data();
-    sv.bfs_locks = bfs_lock.data();
-    sv.bfs_queue_cap = (uint32_t)bfsq.size();
-    sv.bfs_queue_count = 1;
+    cold.bfs_pool = bfsq.data();
+    cold.bfs_locks = bfs_lock.data();
+    cold.bfs_queue_cap = (uint32_t)bfsq.size();
+    cold.bfs_queue_count = 1;
     sv.force_fallback_mask = getenv("SIM_FORCE_FALLBACK") ? (uint32_t)strtoul(getenv("SIM_FORCE_FALLBACK"), 0, 0) : 0xffffffffu;
     if (getenv("SIM_WAVEFRONT")) {
         /* the wavefront schedule with a small slot pool: shade all slots, trace all slots, repeat */
