@@ -56,6 +56,14 @@ constexpr int kTabTreelet = kTabMats + 5 * kTabMatCap; /* nodes [0, kTreeletNode
 constexpr int kTabF4 = kTabTreelet + 4 * (int)kTreeletNodes; /* 503 float4 = 8048 B */
 enum : uint32_t { TAB_PRO = 1u, TAB_LIGHTS = 2u, TAB_PRIM_MATS = 4u, TAB_MATS = 8u };
 
+#ifdef ORT_HOST_SIM
+#define ORT_CONSTANT_AS
+#else
+/* the structs behind these pointers are written by the host before the launch and never by a kernel: the constant
+   address space tells the compiler so, and wave-uniform reads of them become scalar loads (s_load_dwordx8 ...)
+   instead of per-lane vector loads of one address */
+#define ORT_CONSTANT_AS __attribute__((address_space(4)))
+#endif
 /* The part of the scene view that only rare paths read -- the reference test order (bit-equal hit distances) and
    the exact breadth-first fallback -- lives behind one pointer in HBM: as by-value kernel arguments these twenty
    scalar registers were spilled to vector lanes and back all through the shading code. */
@@ -91,7 +99,7 @@ struct SceneView {
     /* reference-compatible octree (ort_reftree.cpp): visibility chains */
     const float4 *chain_boxes; /* 2 per chain entry */
     const uint32_t *tri_chain, *sphere_chain, *box_chain, *cyl_chain;
-    const SceneCold *cold; /* what only the rare paths read (ties, the exact fallback) */
+    const ORT_CONSTANT_AS SceneCold *cold; /* what only the rare paths read (ties, the exact fallback) */
     unsigned long long *util; /* diagnostics (ORT_DEBUG_UTIL=1, counters build): per-phase wave-iteration and active-lane sums */
     uint32_t force_fallback_mask; /* tests (ORT_DEBUG_FORCE_FALLBACK): also re-cast rays with (bits(dir.x) & mask) == 0; ~0u = off */
 };
@@ -127,6 +135,16 @@ struct RenderView {
                               (every parked path is a job in progress: the more a wave holds, the longer its tail) */
 };
 
+/* What the kernels receive by value: the handful of render parameters every ray reads; everything else stays in the
+   RenderView in HBM behind `c` (job decoding, pixel addresses, stashes: read once per job or per pixel).  By value the
+   whole RenderView cost ~45 scalar registers, spilled to vector lanes and back all through the lane code. */
+struct RenderHot {
+    int mode, W, H;
+    float rr;
+    int refill_below, descend_below;
+    const ORT_CONSTANT_AS RenderView *c;
+};
+
 /* wavefront mode: per-slot path state in HBM, structure-of-arrays so that a wave's loads and
    stores are coalesced (consecutive lanes = consecutive slots); 112 B per slot */
 struct WfView {
@@ -150,6 +168,7 @@ struct DeviceScene {
     void *light_is_sphere = nullptr;
     void *tab = nullptr; /* image of the LDS tables (kTabF4 float4) */
     void *cold = nullptr; /* SceneCold */
+    void *rv_dev = nullptr; /* the RenderView of the render in flight (RenderHot::c) */
     uint32_t tab_flags = 0;
     uint32_t light_count = 0;
     bool diffuse_only = false; /* no surface material can enter the specular / transmission blocks */
@@ -524,16 +543,16 @@ struct HitState {
 
 /* position of pixel (x, y) in this shard's packed block layout [local block][pixel in block]: blocks are numbered
    row-major over the block grid and dealt round-robin, so the shard's k-th block is block shard_index + k * shard_count */
-ORT_D size_t packed_index(const RenderView &rv, uint32_t x, uint32_t y) {
-    const uint32_t blk = ((y >> 3) - rv.block_y0) * rv.blocks_w + ((x >> 3) - rv.block_x0);
-    return (size_t)((blk - rv.shard_index) / rv.shard_count) * 64u + ((y & 7u) << 3) + (x & 7u);
+ORT_D size_t packed_index(const RenderHot &rv, uint32_t x, uint32_t y) {
+    const uint32_t blk = ((y >> 3) - rv.c->block_y0) * rv.c->blocks_w + ((x >> 3) - rv.c->block_x0);
+    return (size_t)((blk - rv.c->shard_index) / rv.c->shard_count) * 64u + ((y & 7u) << 3) + (x & 7u);
 }
 /* where a job writes pixel (x, y): its partial plane (CHUNK; packed, so a shard keeps 1/N of a frame per plane) or
    the output image (full frame, or packed on request) */
-ORT_D float *pixel_ptr(const RenderView &rv, uint32_t plane, uint32_t x, uint32_t y) {
-    if (rv.mode == JOBS_CHUNK) return rv.partial + ((size_t)plane * rv.my_blocks * 64u + packed_index(rv, x, y)) * 3u;
-    if (rv.packed_out) return rv.out + packed_index(rv, x, y) * 3u;
-    return rv.out + 3u * ((size_t)y * (size_t)rv.W + (size_t)x);
+ORT_D float *pixel_ptr(const RenderHot &rv, uint32_t plane, uint32_t x, uint32_t y) {
+    if (rv.mode == JOBS_CHUNK) return rv.c->partial + ((size_t)plane * rv.c->my_blocks * 64u + packed_index(rv, x, y)) * 3u;
+    if (rv.c->packed_out) return rv.c->out + packed_index(rv, x, y) * 3u;
+    return rv.c->out + 3u * ((size_t)y * (size_t)rv.W + (size_t)x);
 }
 
 /* traversal state of one ray on the fast tree */
@@ -598,7 +617,7 @@ ORT_D void recast_exactly(const SceneView &sv, bool need, V3 org, V3 dir, V3 inv
 }
 
 /* ray.cpp:1215-1221: the point on the focal plane through the centre of pixel pxy = x | y << 16 */
-ORT_D V3 focal_point(const RenderView &rv, uint32_t pxy, V3 cam_p, V3 cam_x, V3 cam_y, V3 cam_z, float focal_length) {
+ORT_D V3 focal_point(const RenderHot &rv, uint32_t pxy, V3 cam_p, V3 cam_x, V3 cam_y, V3 cam_z, float focal_length) {
     float fx = (2.0f * (int)(pxy & 0xffffu) / (float)rv.W) - 1.0f; /* i32 -> f32, as the reference's x, y */
     float fy = (2.0f * (int)(pxy >> 16) / (float)rv.H) - 1.0f;
     V3 to_pixel = normalize(sub(add(scale(fx, cam_x), scale(fy, cam_y)), cam_z));
@@ -609,7 +628,7 @@ ORT_D V3 focal_point(const RenderView &rv, uint32_t pxy, V3 cam_p, V3 cam_x, V3 
    is P.org / P.dir) or has run out of work (returns false).  On entry with P.ps == PS_HIT, h holds
    the resolved closest hit of the ray produced by the previous call. */
 template <bool COUNTERS, bool DIFFUSE = false, bool TABS = false>
-ORT_D bool produce_ray(const SceneView &sv, const RenderView &rv, const float4 *tab, PathState &P, const HitState &h, Counters &c, Prof &pr,
+ORT_D bool produce_ray(const SceneView &sv, const RenderHot &rv, const float4 *tab, PathState &P, const HitState &h, Counters &c, Prof &pr,
                        float *focal_cache = nullptr, int focal_stride = 0) {
     const V3 cam_p = mk(sv.cam[0], sv.cam[1], sv.cam[2]);
     const V3 cam_x = mk(sv.cam[3], sv.cam[4], sv.cam[5]);
@@ -705,46 +724,46 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderView &rv, const float4 *
                 if (px == (P.jxx >> 16)) { px = P.jxx & 0xffffu; py++; }
                 P.pxy = px | (py << 16);
                 if (py == (P.jyp & 0xffffu)) {
-                    if (rv.mode == JOBS_EXPLICIT && rv.final_states) rv.final_states[P.job_index] = P.rng;
+                    if (rv.mode == JOBS_EXPLICIT && rv.c->final_states) rv.c->final_states[P.job_index] = P.rng;
                     P.ps = PS_NEED_JOB;
                 } else {
                     P.ps = PS_PIXEL;
                 }
             }
             if (P.ps == PS_NEED_JOB) {
-                unsigned long long j = ORT_NEXT_JOB(rv.next_job);
-                if (j >= rv.job_count) { P.ps = PS_DONE; break; }
+                unsigned long long j = ORT_NEXT_JOB(rv.c->next_job);
+                if (j >= rv.c->job_count) { P.ps = PS_DONE; break; }
                 if (rv.mode == JOBS_EXPLICIT) {
-                    ort_tile_job jb = rv.jobs[j];
+                    ort_tile_job jb = rv.c->jobs[j];
                     P.job_index = (uint32_t)j;
                     P.jxx = (uint32_t)jb.x0 | ((uint32_t)jb.x1 << 16);
                     P.jyp = (uint32_t)jb.y1;
                     P.pxy = (uint32_t)jb.x0 | ((uint32_t)jb.y0 << 16);
                     P.rng = jb.rng_state; P.spp = jb.spp;
                     if (jb.x1 <= jb.x0 || jb.y1 <= jb.y0) { /* empty rect: the reference loops zero times */
-                        if (rv.final_states) rv.final_states[P.job_index] = P.rng;
+                        if (rv.c->final_states) rv.c->final_states[P.job_index] = P.rng;
                         continue;
                     }
                 } else {
                     /* implicit job space: [chunk k][my 8x8 block b][pixel-in-block p] */
-                    unsigned long long per_chunk = (unsigned long long)rv.my_blocks * 64ull;
+                    unsigned long long per_chunk = (unsigned long long)rv.c->my_blocks * 64ull;
                     uint32_t k = (uint32_t)(j / per_chunk);
                     uint32_t rem = (uint32_t)(j % per_chunk);
-                    uint32_t blk = rv.shard_index + (rem >> 6) * rv.shard_count;
+                    uint32_t blk = rv.c->shard_index + (rem >> 6) * rv.c->shard_count;
                     uint32_t pin = rem & 63u;
-                    int x = (int)((rv.block_x0 + blk % rv.blocks_w) * 8u + (pin & 7u));
-                    int y = (int)((rv.block_y0 + blk / rv.blocks_w) * 8u + (pin >> 3));
-                    if (x < rv.x0 || x >= rv.x1 || y < rv.y0 || y >= rv.y1) continue;
+                    int x = (int)((rv.c->block_x0 + blk % rv.c->blocks_w) * 8u + (pin & 7u));
+                    int y = (int)((rv.c->block_y0 + blk / rv.c->blocks_w) * 8u + (pin >> 3));
+                    if (x < rv.c->x0 || x >= rv.c->x1 || y < rv.c->y0 || y >= rv.c->y1) continue;
                     uint32_t pix = (uint32_t)(y * rv.W + x);
                     P.jxx = (uint32_t)x | ((uint32_t)(x + 1) << 16);
                     P.pxy = (uint32_t)x | ((uint32_t)y << 16);
                     if (rv.mode == JOBS_PIXEL) {
-                        P.rng = job_seed(rv.seed, pix);
-                        P.spp = rv.spp;
+                        P.rng = job_seed(rv.c->seed, pix);
+                        P.spp = rv.c->spp;
                         P.jyp = (uint32_t)(y + 1);
                     } else {
-                        P.rng = job_seed(rv.seed, k * (uint32_t)(rv.W * rv.H) + pix);
-                        P.spp = rv.chunk;
+                        P.rng = job_seed(rv.c->seed, k * (uint32_t)(rv.W * rv.H) + pix);
+                        P.spp = rv.c->chunk;
                         P.jyp = (uint32_t)(y + 1) | (k << 16);
                     }
                 }
@@ -1033,19 +1052,19 @@ ORT_D void resolve_hit(const SceneView &sv, const float4 *tab, V3 org, V3 dir, V
     recast_exactly<COUNTERS>(sv, recast, org, dir, inv_d, lane_id, h, c);
 }
 
-ORT_D void flush_counters(const RenderView &rv, const Counters &c, bool all) {
+ORT_D void flush_counters(const RenderHot &rv, const Counters &c, bool all) {
     if (all) {
-        ORT_COUNT(rv.counters + 0, c.paths);
-        ORT_COUNT(rv.counters + 1, c.rays);
-        ORT_COUNT(rv.counters + 2, c.nodes);
-        ORT_COUNT(rv.counters + 3, c.tris);
-        ORT_COUNT(rv.counters + 4, c.analytic);
+        ORT_COUNT(rv.c->counters + 0, c.paths);
+        ORT_COUNT(rv.c->counters + 1, c.rays);
+        ORT_COUNT(rv.c->counters + 2, c.nodes);
+        ORT_COUNT(rv.c->counters + 3, c.tris);
+        ORT_COUNT(rv.c->counters + 4, c.analytic);
     }
 }
 
 /* persistent mode: one lane runs jobs until the job space is empty */
 template <bool COUNTERS, bool DIFFUSE = false, bool TABS = false>
-ORT_D void pt_lane(const SceneView &sv, const RenderView &rv, const float4 *tab, uint32_t *lds_stack, float *lds_focal, const int tid,
+ORT_D void pt_lane(const SceneView &sv, const RenderHot &rv, const float4 *tab, uint32_t *lds_stack, float *lds_focal, const int tid,
                    const uint32_t lane_id, bool prof_on = false) {
     uint32_t spill[kSpillStack];
     Prof pr;
@@ -1115,7 +1134,7 @@ ORT_D void stash_store(const Stash &st, uint32_t slot, const PathState &P, const
     r[8u * cap] = make_float4(focal_cache[kBlock], focal_cache[2 * kBlock], 0.0f, 0.0f);
 }
 
-ORT_D void stash_load(const Stash &st, uint32_t slot, const RenderView &rv, PathState &P, HitState &h, Trav &T, float *focal_cache) {
+ORT_D void stash_load(const Stash &st, uint32_t slot, const RenderHot &rv, PathState &P, HitState &h, Trav &T, float *focal_cache) {
     const float4 *r = st.rec + slot;
     const uint32_t cap = st.cap;
     const float4 a = r[0], b = r[cap], c = r[2u * cap], d = r[3u * cap], e = r[4u * cap], f = r[5u * cap], g = r[6u * cap];
@@ -1129,7 +1148,7 @@ ORT_D void stash_load(const Stash &st, uint32_t slot, const RenderView &rv, Path
     const uint32_t sm = om_f32_bits(g.w);
     P.sample = sm & 0x7fffffffu; P.primary = (sm >> 31) != 0u;
     P.jxx = (P.pxy & 0xffffu) | (((P.pxy & 0xffffu) + 1u) << 16); /* implicit jobs are single pixels */
-    P.spp = (rv.mode == JOBS_PIXEL) ? rv.spp : rv.chunk;
+    P.spp = (rv.mode == JOBS_PIXEL) ? rv.c->spp : rv.c->chunk;
     P.job_index = 0;
     P.ps = PS_HIT;
     T.inv_d = mk(i.x, i.y, i.z);
@@ -1137,7 +1156,7 @@ ORT_D void stash_load(const Stash &st, uint32_t slot, const RenderView &rv, Path
 }
 
 template <bool COUNTERS, bool DIFFUSE, bool TABS>
-ORT_D void pt_lane_x(const SceneView &sv, const RenderView &rv, const float4 *tab, uint32_t *lds_stack, float *lds_focal, const int tid,
+ORT_D void pt_lane_x(const SceneView &sv, const RenderHot &rv, const float4 *tab, uint32_t *lds_stack, float *lds_focal, const int tid,
                      const uint32_t lane_id, bool prof_on) {
     uint32_t spill[kSpillStack];
     Prof pr;
@@ -1150,11 +1169,11 @@ ORT_D void pt_lane_x(const SceneView &sv, const RenderView &rv, const float4 *ta
     bool tracing = false;
 
     const uint32_t wave = lane_id >> 6;
-    float4 *wbase = rv.stash + (size_t)wave * rv.stash_wave_f4;
+    float4 *wbase = rv.c->stash + (size_t)wave * rv.c->stash_wave_f4;
     Stash L, R;
-    L.rec = wbase; L.cap = rv.capL;
-    L.stk = (uint32_t *)(wbase + kStashVecs * rv.capL);
-    R.rec = wbase + (kStashVecs + (uint32_t)kLdsStack / 4u) * rv.capL; R.cap = rv.capR; R.stk = nullptr;
+    L.rec = wbase; L.cap = rv.c->capL;
+    L.stk = (uint32_t *)(wbase + kStashVecs * rv.c->capL);
+    R.rec = wbase + (kStashVecs + (uint32_t)kLdsStack / 4u) * rv.c->capL; R.cap = rv.c->capR; R.stk = nullptr;
     uint32_t ltop = 0, rtop = 0; /* wave-uniform */
     float *focal_cache = lds_focal + tid;
 
@@ -1169,7 +1188,7 @@ ORT_D void pt_lane_x(const SceneView &sv, const RenderView &rv, const float4 *ta
         /* once the job space is empty nothing is parked any more (every parked path is a job some lane still has to
            finish): lanes without a path take parked ones, finished rays first, and everything else carries on */
         const bool endgame = __ballot(P.ps == PS_DONE) != 0ull;
-        bool long_phase = !endgame && ltop > 0u && (n_tr + ltop >= rv.long_min || drain);
+        bool long_phase = !endgame && ltop > 0u && (n_tr + ltop >= rv.c->long_min || drain);
         if (endgame) {
             const bool is_free = !tracing && P.ps != PS_HIT;
             const unsigned long long m_recv = __ballot(is_free);
@@ -1242,7 +1261,7 @@ ORT_D void pt_lane_x(const SceneView &sv, const RenderView &rv, const float4 *ta
             rtop -= n_recv < rtop ? n_recv : rtop;
         }
         /* ---- shade: only outside a traversal phase, so that it runs with (nearly) all lanes ---- */
-        const bool hold = P.ps == PS_NEED_JOB && ltop + rtop >= rv.inflight_cap; /* no new job for now */
+        const bool hold = P.ps == PS_NEED_JOB && ltop + rtop >= rv.c->inflight_cap; /* no new job for now */
         if (!long_phase && !tracing && !hold) {
             ORT_UTIL(sv, 3, true);
             ORT_UTIL(sv, 4, P.ps == PS_HIT);
@@ -1258,7 +1277,7 @@ ORT_D void pt_lane_x(const SceneView &sv, const RenderView &rv, const float4 *ta
         if (__ballot(P.ps != PS_DONE || tracing) == 0ull && ltop == 0u && rtop == 0u) break;
         /* in a traversal phase come back for more parked rays when half the lanes have finished; otherwise (and once
            L is empty) when only stragglers are left, which then park */
-        const int below = (long_phase && ltop > 0u) ? (int)rv.long_refill : rv.refill_below;
+        const int below = (long_phase && ltop > 0u) ? (int)rv.c->long_refill : rv.refill_below;
         if (tracing) tracing = traverse<COUNTERS, kLdsStack, kBlock, TABS>(sv, P.org, P.dir, T, h, lds_stack, spill, tid, below, rv.descend_below, c, pr, kNoPrim, tab);
     }
     flush_counters(rv, c, COUNTERS);
@@ -1272,7 +1291,7 @@ constexpr int kWfSpill = 48;
 
 /* one slot: resume its path, produce the next ray, store everything back; returns true if a ray was produced */
 template <bool COUNTERS>
-ORT_D bool wf_shade_slot(const SceneView &sv, const RenderView &rv, const float4 *tab, const WfView &wf, uint32_t i, Counters &c) {
+ORT_D bool wf_shade_slot(const SceneView &sv, const RenderHot &rv, const float4 *tab, const WfView &wf, uint32_t i, Counters &c) {
     uint32_t fl = wf.flags[i];
     PathState P;
     P.ps = (int)(fl & 7u);
@@ -1326,20 +1345,20 @@ ORT_D void wf_trace_slot(const SceneView &sv, const float4 *tab, const WfView &w
 }
 
 /* pixel = (sum over k of partial[k], in k order) / nchunks for one pixel (CHUNK policy) */
-ORT_D void combine_pixel(const RenderView &rv, unsigned long long idx) {
-    uint32_t blk = rv.shard_index + (uint32_t)(idx >> 6) * rv.shard_count;
+ORT_D void combine_pixel(const RenderHot &rv, unsigned long long idx) {
+    uint32_t blk = rv.c->shard_index + (uint32_t)(idx >> 6) * rv.c->shard_count;
     uint32_t pin = (uint32_t)(idx & 63ull);
-    int x = (int)((rv.block_x0 + blk % rv.blocks_w) * 8u + (pin & 7u));
-    int y = (int)((rv.block_y0 + blk / rv.blocks_w) * 8u + (pin >> 3));
-    if (x < rv.x0 || x >= rv.x1 || y < rv.y0 || y >= rv.y1) return;
-    const size_t plane = (size_t)rv.my_blocks * 64u * 3u; /* partial planes are packed: idx is the pixel's place in each */
+    int x = (int)((rv.c->block_x0 + blk % rv.c->blocks_w) * 8u + (pin & 7u));
+    int y = (int)((rv.c->block_y0 + blk / rv.c->blocks_w) * 8u + (pin >> 3));
+    if (x < rv.c->x0 || x >= rv.c->x1 || y < rv.c->y0 || y >= rv.c->y1) return;
+    const size_t plane = (size_t)rv.c->my_blocks * 64u * 3u; /* partial planes are packed: idx is the pixel's place in each */
     V3 acc = mk(0, 0, 0);
-    for (uint32_t k = 0; k < rv.nchunks; ++k) {
-        const float *p = rv.partial + (size_t)k * plane + 3u * (size_t)idx;
+    for (uint32_t k = 0; k < rv.c->nchunks; ++k) {
+        const float *p = rv.c->partial + (size_t)k * plane + 3u * (size_t)idx;
         acc = add(acc, mk(p[0], p[1], p[2]));
     }
-    acc = divs(acc, (float)rv.nchunks);
-    float *o = rv.packed_out ? rv.out + 3u * (size_t)idx : rv.out + 3u * ((size_t)y * (size_t)rv.W + (size_t)x);
+    acc = divs(acc, (float)rv.c->nchunks);
+    float *o = rv.c->packed_out ? rv.c->out + 3u * (size_t)idx : rv.c->out + 3u * ((size_t)y * (size_t)rv.W + (size_t)x);
     o[0] = acc.x; o[1] = acc.y; o[2] = acc.z;
 }
 
@@ -1358,7 +1377,7 @@ __device__ __forceinline__ void fill_tab(const SceneView &sv, float4 *lds_tab) {
 
 template <bool COUNTERS, bool DIFFUSE, bool TABS>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(ORT_WAVES_PER_EU, ORT_WAVES_PER_EU)))
-pt_persistent(SceneView sv, RenderView rv) {
+pt_persistent(SceneView sv, RenderHot rv) {
     __shared__ uint32_t lds_stack[kLdsStack * kBlock];
     __shared__ float lds_focal[3 * kBlock]; /* focal[component][lane] */
     __shared__ float4 lds_tab[TABS ? kTabF4 : 1];
@@ -1379,7 +1398,7 @@ pt_persistent(SceneView sv, RenderView rv) {
 /* the same with the ray exchange (pt_lane_x): implicit job spaces only, LDS tables required */
 template <bool COUNTERS, bool DIFFUSE>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(ORT_WAVES_PER_EU, ORT_WAVES_PER_EU)))
-pt_persistent_x(SceneView sv, RenderView rv) {
+pt_persistent_x(SceneView sv, RenderHot rv) {
     __shared__ uint32_t lds_stack[kLdsStack * kBlock];
     __shared__ float lds_focal[3 * kBlock];
     __shared__ float4 lds_tab[kTabF4];
@@ -1399,7 +1418,7 @@ pt_persistent_x(SceneView sv, RenderView rv) {
 
 /* wavefront kernels: fixed-size grids, grid-stride over the slots */
 template <bool COUNTERS>
-__global__ void __launch_bounds__(kBlock) wf_shade(SceneView sv, RenderView rv, WfView wf, int count_active) {
+__global__ void __launch_bounds__(kBlock) wf_shade(SceneView sv, RenderHot rv, WfView wf, int count_active) {
     const float4 *lds_tab = nullptr; /* the wavefront kernels read the tables from HBM */
     Counters c;
     unsigned long long produced = 0;
@@ -1411,7 +1430,7 @@ __global__ void __launch_bounds__(kBlock) wf_shade(SceneView sv, RenderView rv, 
 }
 
 template <bool COUNTERS>
-__global__ void __launch_bounds__(kBlock) wf_trace(SceneView sv, RenderView rv, WfView wf) {
+__global__ void __launch_bounds__(kBlock) wf_trace(SceneView sv, RenderHot rv, WfView wf) {
     __shared__ uint32_t lds_stack[kWfLdsStack * kBlock];
     const float4 *lds_tab = nullptr;
     uint32_t spill[kWfSpill];
@@ -1500,9 +1519,9 @@ __global__ void unit_eval(const uint32_t *records, uint32_t n, float *out) {
     for (int k = 0; k < 8; ++k) out[8u * i + k] = o[k];
 }
 
-__global__ void combine_chunks(RenderView rv) {
+__global__ void combine_chunks(RenderHot rv) {
     unsigned long long idx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (unsigned long long)rv.my_blocks * 64ull) return;
+    if (idx >= (unsigned long long)rv.c->my_blocks * 64ull) return;
     combine_pixel(rv, idx);
 }
 
@@ -1537,7 +1556,7 @@ void device_release(Scene *scene) {
     if (!d) return;
     (void)hipSetDevice(d->device);
     void *ptrs[] = {d->nodes, d->tris, d->tri_mat, d->spheres, d->sphere_mat, d->boxes, d->box_mat, d->cyls, d->cyl_mat,
-                    d->materials, d->light_is_sphere, d->tab, d->cold, d->ref_nodes, d->ref_recs, d->chain_boxes, d->tri_chain, d->sphere_chain,
+                    d->materials, d->light_is_sphere, d->tab, d->cold, d->rv_dev, d->ref_nodes, d->ref_recs, d->chain_boxes, d->tri_chain, d->sphere_chain,
                     d->box_chain, d->cyl_chain, d->tri_order, d->sphere_order, d->box_order, d->cyl_order, d->bfs_pool, d->bfs_locks, d->ctrl, d->partial, d->staging, d->jobs, d->states};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -1666,6 +1685,7 @@ int device_upload(Scene *scene, int device, std::string *err) {
         cold.bfs_pool = (uint32_t *)d->bfs_pool; cold.bfs_locks = (uint32_t *)d->bfs_locks;
         cold.bfs_queue_cap = d->bfs_queue_cap; cold.bfs_queue_count = d->bfs_queue_count;
         cold.fallback_counters = d->ctrl + 6;
+        ORT_HIP(hipMalloc(&d->rv_dev, sizeof(RenderView)));
         ORT_HIP(hipMalloc(&d->cold, sizeof(SceneCold)));
         ORT_HIP(hipMemcpy(d->cold, &cold, sizeof(SceneCold), hipMemcpyHostToDevice));
     }
@@ -1732,9 +1752,9 @@ static int ensure(void **ptr, size_t *have, size_t need, std::string *err) {
    hit) until no slot produces a ray any more.  The host only learns "finished" by reading a
    counter, so it launches iterations in batches and checks after each batch. */
 template <bool COUNTERS>
-static int launch_wavefront(DeviceScene *d, const SceneView &sv, const RenderView &rv, hipStream_t stream, std::string *err) {
+static int launch_wavefront(DeviceScene *d, const SceneView &sv, const RenderView &rvf, const RenderHot &rv, hipStream_t stream, std::string *err) {
     const uint32_t kMaxSlots = 1u << 21;
-    unsigned long long want = rv.job_count < kMaxSlots ? rv.job_count : kMaxSlots;
+    unsigned long long want = rvf.job_count < kMaxSlots ? rvf.job_count : kMaxSlots;
     uint32_t S = (uint32_t)((want + kBlock - 1) / kBlock) * kBlock;
     if (S == 0) S = kBlock;
     const size_t per_slot = 16 + 8 + 16 + 4 + 16 + 16 + 16 + 16 + 4;
@@ -1817,7 +1837,7 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
     sv.box_chain = (const uint32_t *)d->box_chain; sv.cyl_chain = (const uint32_t *)d->cyl_chain;
     const char *ff = getenv("ORT_DEBUG_FORCE_FALLBACK");
     sv.force_fallback_mask = ff ? (uint32_t)strtoul(ff, nullptr, 0) : 0xffffffffu;
-    sv.cold = (const SceneCold *)d->cold;
+    sv.cold = (const ORT_CONSTANT_AS SceneCold *)d->cold;
     const bool want_util = getenv("ORT_DEBUG_UTIL") != nullptr; /* developer diagnostics, counters build only */
     sv.util = want_util ? d->ctrl + 8 : nullptr;
     ort_camera cam;
@@ -1892,25 +1912,21 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
     unsigned int grid = (unsigned int)((lanes_wanted + kBlock - 1) / kBlock);
     if (grid > max_blocks) grid = max_blocks;
     if (grid == 0) grid = 1;
-    if (stats) ORT_HIP(hipEventRecord(d->ev0, stream));
     const char *mode_env = getenv("ORT_MODE"); /* "wavefront" | "persistent"; results are identical */
     const bool wavefront = mode_env ? (strcmp(mode_env, "wavefront") == 0) : false;
-    if (wavefront) {
-        rc = counters ? launch_wavefront<true>(d, sv, rv, stream, err) : launch_wavefront<false>(d, sv, rv, stream, err);
-        if (rc) return rc;
-    } else {
-        const char *kenv = getenv("ORT_KERNEL"); /* "general" forces the all-lobes kernel (A/B runs; same results) */
-        const bool diffuse = d->diffuse_only && !(kenv && strcmp(kenv, "general") == 0);
-        /* TABS: the scene's small tables all fit their LDS slots (every scene of this repository); otherwise HBM */
-        const uint32_t all_tabs = TAB_PRO | TAB_LIGHTS | TAB_PRIM_MATS | TAB_MATS;
-        const char *tenv = getenv("ORT_LDS_TABLES"); /* "0": read them from HBM anyway (A/B runs; same results) */
-        const bool tabs = (d->tab_flags & all_tabs) == all_tabs && !(tenv && atoi(tenv) == 0);
-#define ORT_LAUNCH(C, D, T) hipLaunchKernelGGL((pt_persistent<C, D, T>), dim3(grid), dim3(kBlock), 0, stream, sv, rv)
+    const char *kenv = getenv("ORT_KERNEL"); /* "general" forces the all-lobes kernel (A/B runs; same results) */
+    const bool diffuse = d->diffuse_only && !(kenv && strcmp(kenv, "general") == 0);
+    /* TABS: the scene's small tables all fit their LDS slots (every scene of this repository); otherwise HBM */
+    const uint32_t all_tabs = TAB_PRO | TAB_LIGHTS | TAB_PRIM_MATS | TAB_MATS;
+    const char *tenv = getenv("ORT_LDS_TABLES"); /* "0": read them from HBM anyway (A/B runs; same results) */
+    const bool tabs = (d->tab_flags & all_tabs) == all_tabs && !(tenv && atoi(tenv) == 0);
+    bool exch = false;
+    if (!wavefront) {
         /* ray exchange (pt_lane_x): opt-in with ORT_EXCHANGE=1 -- bit-identical, 60 of 64 lanes in the shading
            pass instead of 53 and leaf visits four times better filled, but the parking traffic and 20 more spilled
            registers cost what that gains (profiles/r02_tuning.md); implicit job spaces with the LDS tables only */
         const char *xenv = getenv("ORT_EXCHANGE");
-        const bool exch = tabs && rv.mode != JOBS_EXPLICIT && (xenv && atoi(xenv) != 0) && (!counters || (want_util && diffuse));
+        exch = tabs && rv.mode != JOBS_EXPLICIT && (xenv && atoi(xenv) != 0) && (!counters || (want_util && diffuse));
         if (exch) {
             const char *e;
             rv.capL = 128; rv.capR = 192;
@@ -1924,9 +1940,25 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
             const size_t need = (size_t)d->max_blocks * (kBlock / 64) * rv.stash_wave_f4 * sizeof(float4);
             if ((rc = ensure(&d->stash, &d->stash_bytes, need, err))) return rc;
             rv.stash = (float4 *)d->stash;
-            if (counters) hipLaunchKernelGGL((pt_persistent_x<true, true>), dim3(grid), dim3(kBlock), 0, stream, sv, rv); /* diagnostics: probes of the diffuse flavour */
-            else if (diffuse) hipLaunchKernelGGL((pt_persistent_x<false, true>), dim3(grid), dim3(kBlock), 0, stream, sv, rv);
-            else hipLaunchKernelGGL((pt_persistent_x<false, false>), dim3(grid), dim3(kBlock), 0, stream, sv, rv);
+        }
+    }
+    /* the RenderView goes to HBM (pageable source: the copy is staged before the call returns); the kernels get the few
+       fields every ray reads by value and a pointer to the rest */
+    ORT_HIP(hipMemcpyAsync(d->rv_dev, &rv, sizeof(RenderView), hipMemcpyHostToDevice, stream));
+    RenderHot hot{};
+    hot.mode = rv.mode; hot.W = rv.W; hot.H = rv.H; hot.rr = rv.rr;
+    hot.refill_below = rv.refill_below; hot.descend_below = rv.descend_below;
+    hot.c = (const ORT_CONSTANT_AS RenderView *)d->rv_dev;
+    if (stats) ORT_HIP(hipEventRecord(d->ev0, stream));
+    if (wavefront) {
+        rc = counters ? launch_wavefront<true>(d, sv, rv, hot, stream, err) : launch_wavefront<false>(d, sv, rv, hot, stream, err);
+        if (rc) return rc;
+    } else {
+#define ORT_LAUNCH(C, D, T) hipLaunchKernelGGL((pt_persistent<C, D, T>), dim3(grid), dim3(kBlock), 0, stream, sv, hot)
+        if (exch) {
+            if (counters) hipLaunchKernelGGL((pt_persistent_x<true, true>), dim3(grid), dim3(kBlock), 0, stream, sv, hot); /* diagnostics: probes of the diffuse flavour */
+            else if (diffuse) hipLaunchKernelGGL((pt_persistent_x<false, true>), dim3(grid), dim3(kBlock), 0, stream, sv, hot);
+            else hipLaunchKernelGGL((pt_persistent_x<false, false>), dim3(grid), dim3(kBlock), 0, stream, sv, hot);
         } else
         if (counters && diffuse && want_util) { if (tabs) ORT_LAUNCH(true, true, true); else ORT_LAUNCH(true, true, false); }
         else if (counters) { if (tabs) ORT_LAUNCH(true, false, true); else ORT_LAUNCH(true, false, false); }
@@ -1938,7 +1970,7 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
     if (rv.mode == JOBS_CHUNK) {
         unsigned long long total = (unsigned long long)rv.my_blocks * 64ull;
         unsigned int cgrid = (unsigned int)((total + 255) / 256);
-        if (cgrid) hipLaunchKernelGGL(combine_chunks, dim3(cgrid), dim3(256), 0, stream, rv);
+        if (cgrid) hipLaunchKernelGGL(combine_chunks, dim3(cgrid), dim3(256), 0, stream, hot);
         ORT_HIP(hipGetLastError());
     }
     if (stats) ORT_HIP(hipEventRecord(d->ev1, stream));

@@ -98,6 +98,9 @@ int main(int argc, char **argv) {
         rv.mode = JOBS_EXPLICIT; rv.jobs = jobs.data(); rv.job_count = jobs.size(); rv.final_states = finals.data();
     }
     std::vector<uint32_t> pix_rng((size_t)W * H, 0);
+    RenderHot hot{};
+    hot.mode = rv.mode; hot.W = rv.W; hot.H = rv.H; hot.rr = rv.rr; hot.refill_below = rv.refill_below; hot.descend_below = rv.descend_below;
+    hot.c = &rv;
     if (getenv("SIM_RAY_LOG")) { g_ray_log = fopen(getenv("SIM_RAY_LOG"), "wb"); g_dbg_x = atoi(getenv("SIM_X")); g_dbg_y = atoi(getenv("SIM_Y")); }
     if (getenv("SIM_DUMP_RNG")) { g_pixel_rng = pix_rng.data(); g_W = W; }
     std::vector<uint32_t> lds(kLdsStack * kBlock);
@@ -123,16 +126,16 @@ int main(int argc, char **argv) {
         Counters c;
         for (;;) {
             unsigned long long produced = 0;
-            for (uint32_t i = 0; i < S; ++i) produced += wf_shade_slot<true>(sv, rv, nullptr, wf, i, c) ? 1 : 0;
+            for (uint32_t i = 0; i < S; ++i) produced += wf_shade_slot<true>(sv, hot, nullptr, wf, i, c) ? 1 : 0;
             if (!produced) break;
             for (uint32_t i = 0; i < S; ++i) wf_trace_slot<true>(sv, nullptr, wf, i, 0, wlds.data(), wspill.data(), 0, c);
         }
-        flush_counters(rv, c, true);
+        flush_counters(hot, c, true);
     } else
-    if (getenv("SIM_DIFFUSE")) pt_lane<true, true>(sv, rv, nullptr, lds.data(), lds_focal.data(), 0, 0); /* caller vouches for Ks = Kt = 0 */
-    else pt_lane<true>(sv, rv, nullptr, lds.data(), lds_focal.data(), 0, 0); /* TABS = false: the small tables are read from their arrays */
+    if (getenv("SIM_DIFFUSE")) pt_lane<true, true>(sv, hot, nullptr, lds.data(), lds_focal.data(), 0, 0); /* caller vouches for Ks = Kt = 0 */
+    else pt_lane<true>(sv, hot, nullptr, lds.data(), lds_focal.data(), 0, 0); /* TABS = false: the small tables are read from their arrays */
     if (rv.mode == JOBS_CHUNK)
-        for (unsigned long long i = 0; i < (unsigned long long)rv.my_blocks * 64; ++i) combine_pixel(rv, i);
+        for (unsigned long long i = 0; i < (unsigned long long)rv.my_blocks * 64; ++i) combine_pixel(hot, i);
     double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     fprintf(stderr, "sim: %.2fs paths %llu rays %llu node_tests %llu tri_tests %llu analytic %llu fallback %llu overflow %llu%s\n", sec, ctrl[1], ctrl[2], ctrl[3], ctrl[4], ctrl[5], ctrl[6], ctrl[7],
             finals.empty() ? "" : (" final_rng " + std::to_string(finals.back())).c_str());
