@@ -1922,11 +1922,15 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
     const bool tabs = (d->tab_flags & all_tabs) == all_tabs && !(tenv && atoi(tenv) == 0);
     bool exch = false;
     if (!wavefront) {
-        /* ray exchange (pt_lane_x): opt-in with ORT_EXCHANGE=1 -- bit-identical, 60 of 64 lanes in the shading
-           pass instead of 53 and leaf visits four times better filled, but the parking traffic and 20 more spilled
-           registers cost what that gains (profiles/r02_tuning.md); implicit job spaces with the LDS tables only */
+        /* ray exchange (pt_lane_x): bit-identical; 60 of 64 lanes in the shading pass instead of 53 and leaf
+           visits four times better filled, against the parking traffic.  On by itself where it is a gain
+           (profiles/r02_tuning.md): the diffuse flavour (the all-lobes one spills too much around the exchange) on
+           launches of at least 24 jobs per lane -- every parked path is a job in progress, so a wave's tail grows with
+           what it has parked, which short launches and 8-way shards cannot amortise.  ORT_EXCHANGE=0 / 1 forces it. */
         const char *xenv = getenv("ORT_EXCHANGE");
-        exch = tabs && rv.mode != JOBS_EXPLICIT && (xenv && atoi(xenv) != 0) && (!counters || (want_util && diffuse));
+        const bool worth_it = diffuse && rv.job_count >= 24ull * (unsigned long long)grid * kBlock;
+        exch = tabs && rv.mode != JOBS_EXPLICIT && (xenv ? atoi(xenv) != 0 : worth_it) && (!counters || (want_util && diffuse));
+        if (exch && !getenv("ORT_REFILL_BELOW")) rv.refill_below = 16; /* stragglers park instead of idling: leave the loop a little earlier */
         if (exch) {
             const char *e;
             rv.capL = 128; rv.capR = 192;

@@ -38,6 +38,21 @@ def test_full_frame_determinism_and_shards(api, gpu_scene):
     assert np.isfinite(a).all()
 
 
+def test_full_frame_ray_exchange(api, gpu_scene, monkeypatch):
+    """the whole 1920x1080 frame (2 M pixels, 32 spp in 8-sample jobs = 32 jobs per lane: the launch shape on which the
+    exchange switches itself on): exchange forced off == forced on == left to itself, bit for bit"""
+    scene = gpu_scene("c3_bunny_room")
+    spp, chunk, seed = 32, 8, 2025
+    monkeypatch.setenv("ORT_EXCHANGE", "0")
+    a, _ = scene.render(W, H, spp, seed, "chunk", chunk=chunk)
+    monkeypatch.setenv("ORT_EXCHANGE", "1")
+    b, _ = scene.render(W, H, spp, seed, "chunk", chunk=chunk)
+    assert_bits_equal(a, b, "exchange on vs off, full frame")
+    monkeypatch.delenv("ORT_EXCHANGE")
+    c, _ = scene.render(W, H, spp, seed, "chunk", chunk=chunk)
+    assert_bits_equal(a, c, "default launch policy, full frame")
+
+
 def test_headline_config_window_matches_oracle(api, oracle, gpu_scene):
     """BASELINE.json's headline parameters themselves -- 1920x1080, 1024 spp as 16 serial 64-sample jobs per pixel --
     on a 24x16 window over the bunny (393 216 paths: ~1 s of oracle time): bit-equal to the oracle, and chunk 0 is the

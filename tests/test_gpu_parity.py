@@ -178,6 +178,30 @@ def test_diffuse_kernel_equals_general_kernel(api, gpu_scene, monkeypatch, name)
     assert_bits_equal(a, b)
 
 
+@pytest.mark.parametrize("name,policy,w,h,spp,chunk", [("c3_bunny_room", "chunk", 200, 120, 32, 8), ("c4_dwarf_room", "pixel", 160, 90, 24, 0),
+                                                     ("testscene", "chunk", 128, 72, 16, 4), ("glass_room", "chunk", 128, 72, 16, 8)])
+def test_ray_exchange_equals_plain_loop(api, oracle, gpu_scene, monkeypatch, name, policy, w, h, spp, chunk):
+    """the ray exchange (stragglers park in the wave's stash in HBM, the shading pass runs full, parked rays are traversed
+    64 at a time; on by itself only for long diffuse launches) only changes WHICH lane advances a path and WHEN: same
+    bits as the plain loop and as the oracle, in both kernel flavours, with the long-phase threshold at its default
+    and squeezed so that every mechanism (parking with deep stacks, refills, the drain at the end) is exercised"""
+    scene = gpu_scene(name)
+    monkeypatch.setenv("ORT_EXCHANGE", "0")
+    a, _ = scene.render(w, h, spp, 17, policy, chunk=chunk)
+    monkeypatch.setenv("ORT_EXCHANGE", "1")
+    b, _ = scene.render(w, h, spp, 17, policy, chunk=chunk)
+    assert_bits_equal(a, b, "exchange on vs off")
+    for knobs in ({"ORT_LONG_MIN": "16", "ORT_INFLIGHT_CAP": "16", "ORT_REFILL_BELOW": "40"}, {"ORT_LONG_MIN": "128", "ORT_INFLIGHT_CAP": "128", "ORT_LONG_REFILL": "60"}):
+        for k, v in knobs.items():
+            monkeypatch.setenv(k, v)
+        c, _ = scene.render(w, h, spp, 17, policy, chunk=chunk)
+        assert_bits_equal(a, c, "exchange with %s" % knobs)
+        for k in knobs:
+            monkeypatch.delenv(k)
+    ref, _ = oracle.OracleScene(scene.flatten(w, h)).render(w, h, spp, 17, policy, chunk=max(chunk, 1), threads=16)
+    assert_bits_equal(b, ref, "exchange vs oracle")
+
+
 def test_determinism(api, gpu_scene):
     scene = gpu_scene("testscene")
     a, _ = scene.render(128, 72, 8, 1, "chunk", chunk=4)
