@@ -34,7 +34,8 @@ constexpr int kBlock = 256;      /* 4 waves */
 #define ORT_LDS_STACK 24
 #endif
 constexpr int kLdsStack = ORT_LDS_STACK; /* entries per lane in LDS: 24 * 256 * 4 B = 24 KB per block */
-constexpr int kSpillStack = 40;  /* scratch tail; ort_tree.cpp bounds the depth at 60 */
+constexpr int kSpillStack = 40;  /* scratch tail */
+static_assert(kLdsStack - 4 + kSpillStack >= (int)kTreeDepthBudget, "the re-traversal of resolve_hit must hold a tree of kTreeDepthBudget levels");
 constexpr uint32_t kBfsPoolQueues = 256;      /* queues of the breadth-first fallback, shared by all lanes */
 constexpr size_t kBfsPoolBytes = 512u << 20; /* at most; a queue holds one entry per reference-tree node */
 
@@ -1288,6 +1289,7 @@ ORT_D void pt_lane_x(const SceneView &sv, const RenderHot &rv, const float4 *tab
 constexpr uint32_t WF_PRIMARY = 8u, WF_HAS_RAY = 16u;
 constexpr int kWfLdsStack = 16; /* trace kernel: 16 LDS entries per lane (16 KB per 256-lane block), tail in scratch */
 constexpr int kWfSpill = 48;
+static_assert(kWfLdsStack - 4 + kWfSpill >= (int)kTreeDepthBudget, "wavefront trace stack must hold a tree of kTreeDepthBudget levels");
 
 /* one slot: resume its path, produce the next ray, store everything back; returns true if a ray was produced */
 template <bool COUNTERS>

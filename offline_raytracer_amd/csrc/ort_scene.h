@@ -43,6 +43,10 @@ constexpr uint32_t SPHERE_BELOW_BIT = 0x40000000u;
 constexpr uint32_t NODE_INDEX_MASK = 0x3fffffffu;
 constexpr uint32_t EMPTY_CHILD = 0xffffffffu; /* leaf, kind 7: never visited (box is inverted) */
 constexpr uint32_t MAX_LEAF_PRIMS = 16;
+/* depth of the fast tree = what a traversal stack must hold at most.  ONE constant: ort_tree.cpp builds within it
+   (and refuses a tree that exceeds it), ort_kernels.hip static_asserts that its smallest stack (the re-traversal of
+   resolve_hit: LDS entries minus the four it borrows, plus the scratch tail) holds it */
+constexpr uint32_t kTreeDepthBudget = 60;
 constexpr uint32_t kTreeletNodes = 32; /* the breadth-first top of the fast tree has indices [0, 32): kept in LDS by the kernel */
 
 inline uint32_t make_leaf(uint32_t kind, uint32_t first, uint32_t count) {

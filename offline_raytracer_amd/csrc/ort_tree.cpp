@@ -104,7 +104,7 @@ struct Builder {
     static constexpr int kBins = 16;
     uint32_t kMaxLeafTri = 4;   /* tuning knobs (env ORT_LEAF_TRI / ORT_LEAF_OTHER); results do not depend on them */
     uint32_t kMaxLeafOther = 2;
-    static constexpr uint32_t kDepthBudget = 60; /* traversal stack holds 64 entries */
+    static constexpr uint32_t kDepthBudget = kTreeDepthBudget; /* ort_scene.h: the kernels' smallest traversal stack */
 
     static constexpr float kNodeCost = 1.0f, kPrimCost = 1.2f;
     double sah_sum = 0;
@@ -527,6 +527,10 @@ int build_tree(Scene *scene, std::string *err) {
             tree->nodes.push_back(n);
         }
         tree->sah_cost = (float)(b.sah_sum / b.root_area);
+    }
+    if (tree->max_depth > kTreeDepthBudget) { /* cannot happen (the builder forces median splits near the budget): a tripwire for builder changes */
+        *err = "internal: fast tree deeper than the traversal stacks";
+        return ORT_ERR_UNSUPPORTED;
     }
     renumber_top_levels(tree, kTreeletNodes);
     tree->built = true;

@@ -16,7 +16,7 @@
  * round-to-float, i.e. correctly rounded f32 except in ~1e-6 of cases.
  *
  * The same algorithm is restated for the device in
- * offline_raytracer_amd/csrc/ort_detmath.h; tests/test_detmath.py checks the two
+ * offline_raytracer_amd/csrc/ort_detmath.h; tests/test_oracle_golden.py::test_libm_is_close_to_glibc and the unit tables (op 9) check the two
  * bit for bit.
  */
 #ifndef ORT_ORACLE_DET_MATH_H

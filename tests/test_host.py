@@ -176,7 +176,7 @@ def test_fast_tree_shape(load_scene):
     assert load_scene("testscene").tree_info()["prologue_prims"] == 9  # its nine boxes; spheres and cylinders stay in the tree
     assert ti["leaf_count"] == ti["node_count"] + 1  # binary tree with leaves encoded in child words
     assert ti["max_leaf_prims"] <= 16
-    assert ti["max_depth"] <= 60  # the traversal stack holds 24 (LDS) + 64 (scratch) entries
+    assert ti["max_depth"] <= 60  # kTreeDepthBudget (ort_scene.h): the kernels' smallest stack, 20 LDS + 40 scratch entries
     assert ti["node_bytes"] == ti["node_count"] * 64
 
 
