@@ -34,7 +34,10 @@ constexpr int kBlock = 256;      /* 4 waves */
 #define ORT_LDS_STACK 24
 #endif
 constexpr int kLdsStack = ORT_LDS_STACK; /* entries per lane in LDS: 24 * 256 * 4 B = 24 KB per block */
-constexpr int kSpillStack = 40;  /* scratch tail */
+#ifndef ORT_SPILL_STACK
+#define ORT_SPILL_STACK 40
+#endif
+constexpr int kSpillStack = ORT_SPILL_STACK;  /* scratch tail */
 static_assert(kLdsStack - 4 + kSpillStack >= (int)kTreeDepthBudget, "the re-traversal of resolve_hit must hold a tree of kTreeDepthBudget levels");
 constexpr uint32_t kBfsPoolQueues = 256;      /* queues of the breadth-first fallback, shared by all lanes */
 constexpr size_t kBfsPoolBytes = 512u << 20; /* at most; a queue holds one entry per reference-tree node */
@@ -628,9 +631,11 @@ ORT_D V3 focal_point(const RenderHot &rv, uint32_t pxy, V3 cam_p, V3 cam_x, V3 c
 /* Advance the lane's path state machine until it has produced the next ray (returns true; the ray
    is P.org / P.dir) or has run out of work (returns false).  On entry with P.ps == PS_HIT, h holds
    the resolved closest hit of the ray produced by the previous call. */
-template <bool COUNTERS, bool DIFFUSE = false, bool TABS = false>
+/* IMPLICIT: the caller vouches for an implicit job space (PIXEL / CHUNK policies: every job is one pixel, spp_u
+   samples): the job's rect, its sample count and its index then need no registers of their own */
+template <bool COUNTERS, bool DIFFUSE = false, bool TABS = false, bool IMPLICIT = false>
 ORT_D bool produce_ray(const SceneView &sv, const RenderHot &rv, const float4 *tab, PathState &P, const HitState &h, Counters &c, Prof &pr,
-                       float *focal_cache = nullptr, int focal_stride = 0) {
+                       float *focal_cache = nullptr, int focal_stride = 0, uint32_t spp_u = 0) {
     const V3 cam_p = mk(sv.cam[0], sv.cam[1], sv.cam[2]);
     const V3 cam_x = mk(sv.cam[3], sv.cam[4], sv.cam[5]);
     const V3 cam_y = mk(sv.cam[6], sv.cam[7], sv.cam[8]);
@@ -715,12 +720,16 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderHot &rv, const float4 *t
             /* a lane arrives here after its sample ended (PS_SAMPLE), or with nothing yet (PS_NEED_JOB).
                Pixel write-back, next pixel / next job and the new camera ray all happen in this same
                pass, so the rest of the wave does not wait through a second trip round the loop. */
-            if (P.ps == PS_SAMPLE && P.sample == P.spp) {
+            const uint32_t job_spp = IMPLICIT ? spp_u : P.spp;
+            if (P.ps == PS_SAMPLE && P.sample == job_spp) {
                 /* ray.cpp:1428 */
-                V3 o = divs(P.color, (float)P.spp);
+                V3 o = divs(P.color, (float)job_spp);
                 uint32_t px = P.pxy & 0xffffu, py = P.pxy >> 16;
                 float *p = pixel_ptr(rv, P.jyp >> 16, px, py);
                 p[0] = o.x; p[1] = o.y; p[2] = o.z;
+                if (IMPLICIT) {
+                    P.ps = PS_NEED_JOB; /* a one-pixel job ends with its pixel */
+                } else {
                 px++;
                 if (px == (P.jxx >> 16)) { px = P.jxx & 0xffffu; py++; }
                 P.pxy = px | (py << 16);
@@ -730,11 +739,12 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderHot &rv, const float4 *t
                 } else {
                     P.ps = PS_PIXEL;
                 }
+                }
             }
             if (P.ps == PS_NEED_JOB) {
                 unsigned long long j = ORT_NEXT_JOB(rv.c->next_job);
                 if (j >= rv.c->job_count) { P.ps = PS_DONE; break; }
-                if (rv.mode == JOBS_EXPLICIT) {
+                if (!IMPLICIT && rv.mode == JOBS_EXPLICIT) {
                     ort_tile_job jb = rv.c->jobs[j];
                     P.job_index = (uint32_t)j;
                     P.jxx = (uint32_t)jb.x0 | ((uint32_t)jb.x1 << 16);
@@ -756,15 +766,15 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderHot &rv, const float4 *t
                     int y = (int)((rv.c->block_y0 + blk / rv.c->blocks_w) * 8u + (pin >> 3));
                     if (x < rv.c->x0 || x >= rv.c->x1 || y < rv.c->y0 || y >= rv.c->y1) continue;
                     uint32_t pix = (uint32_t)(y * rv.W + x);
-                    P.jxx = (uint32_t)x | ((uint32_t)(x + 1) << 16);
+                    if (!IMPLICIT) P.jxx = (uint32_t)x | ((uint32_t)(x + 1) << 16);
                     P.pxy = (uint32_t)x | ((uint32_t)y << 16);
                     if (rv.mode == JOBS_PIXEL) {
                         P.rng = job_seed(rv.c->seed, pix);
-                        P.spp = rv.c->spp;
+                        if (!IMPLICIT) P.spp = rv.c->spp;
                         P.jyp = (uint32_t)(y + 1);
                     } else {
                         P.rng = job_seed(rv.c->seed, k * (uint32_t)(rv.W * rv.H) + pix);
-                        P.spp = rv.c->chunk;
+                        if (!IMPLICIT) P.spp = rv.c->chunk;
                         P.jyp = (uint32_t)(y + 1) | (k << 16);
                     }
                 }
@@ -780,7 +790,7 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderHot &rv, const float4 *t
                     focal_cache[0] = f.x; focal_cache[focal_stride] = f.y; focal_cache[2 * focal_stride] = f.z;
                 }
             }
-            if (P.sample == P.spp) continue; /* spp == 0: the reference's sample loop runs zero times */
+            if (P.sample == job_spp) continue; /* spp == 0: the reference's sample loop runs zero times */
             /* ray.cpp:1215-1221: point on the focal plane through the pixel centre: a function of the pixel alone,
                read back from the per-lane cache or (wavefront mode) recomputed -- same expressions, same bits */
             focal = focal_cache ? mk(focal_cache[0], focal_cache[focal_stride], focal_cache[2 * focal_stride])
@@ -1064,10 +1074,11 @@ ORT_D void flush_counters(const RenderHot &rv, const Counters &c, bool all) {
 }
 
 /* persistent mode: one lane runs jobs until the job space is empty */
-template <bool COUNTERS, bool DIFFUSE = false, bool TABS = false>
+template <bool COUNTERS, bool DIFFUSE = false, bool TABS = false, bool IMPLICIT = false>
 ORT_D void pt_lane(const SceneView &sv, const RenderHot &rv, const float4 *tab, uint32_t *lds_stack, float *lds_focal, const int tid,
                    const uint32_t lane_id, bool prof_on = false) {
     uint32_t spill[kSpillStack];
+    const uint32_t spp_u = IMPLICIT ? ((rv.mode == JOBS_PIXEL) ? rv.c->spp : rv.c->chunk) : 0u; /* samples per (one-pixel) job */
     Prof pr;
     pr.on = prof_on;
 #ifndef ORT_HOST_SIM
@@ -1085,7 +1096,7 @@ ORT_D void pt_lane(const SceneView &sv, const RenderHot &rv, const float4 *tab, 
             ORT_PHASE(pr, sv, 7, true);
             if (P.ps == PS_HIT) resolve_hit<COUNTERS, TABS, kLdsStack, kBlock>(sv, tab, P.org, P.dir, T.inv_d, lane_id, h, c, pr, lds_stack, spill, tid);
             ORT_PHASE(pr, sv, 0, P.ps == PS_HIT);
-            tracing = produce_ray<COUNTERS, DIFFUSE, TABS>(sv, rv, tab, P, h, c, pr, lds_focal + tid, kBlock);
+            tracing = produce_ray<COUNTERS, DIFFUSE, TABS, IMPLICIT>(sv, rv, tab, P, h, c, pr, lds_focal + tid, kBlock, spp_u);
             if (tracing) {
                 begin_ray<COUNTERS, TABS, kLdsStack, kBlock>(sv, tab, P, T, h, c, pr, lds_stack, spill, tid);
                 if (COUNTERS) c.rays++;
@@ -1148,9 +1159,6 @@ ORT_D void stash_load(const Stash &st, uint32_t slot, const RenderHot &rv, PathS
     P.pxy = om_f32_bits(g.y); P.jyp = om_f32_bits(g.z);
     const uint32_t sm = om_f32_bits(g.w);
     P.sample = sm & 0x7fffffffu; P.primary = (sm >> 31) != 0u;
-    P.jxx = (P.pxy & 0xffffu) | (((P.pxy & 0xffffu) + 1u) << 16); /* implicit jobs are single pixels */
-    P.spp = (rv.mode == JOBS_PIXEL) ? rv.c->spp : rv.c->chunk;
-    P.job_index = 0;
     P.ps = PS_HIT;
     T.inv_d = mk(i.x, i.y, i.z);
     focal_cache[0] = i.w; focal_cache[kBlock] = j.x; focal_cache[2 * kBlock] = j.y;
@@ -1169,7 +1177,8 @@ ORT_D void pt_lane_x(const SceneView &sv, const RenderHot &rv, const float4 *tab
     Counters c;
     bool tracing = false;
 
-    const uint32_t wave = lane_id >> 6;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lane_id >> 6)); /* wave-uniform: the stash addresses stay in scalar registers */
+    const uint32_t spp_u = (rv.mode == JOBS_PIXEL) ? rv.c->spp : rv.c->chunk;                /* samples per (one-pixel) job */
     float4 *wbase = rv.c->stash + (size_t)wave * rv.c->stash_wave_f4;
     Stash L, R;
     L.rec = wbase; L.cap = rv.c->capL;
@@ -1269,7 +1278,7 @@ ORT_D void pt_lane_x(const SceneView &sv, const RenderHot &rv, const float4 *tab
             ORT_PHASE(pr, sv, 7, true);
             if (P.ps == PS_HIT) resolve_hit<COUNTERS, TABS, kLdsStack, kBlock>(sv, tab, P.org, P.dir, T.inv_d, lane_id, h, c, pr, lds_stack, spill, tid);
             ORT_PHASE(pr, sv, 0, P.ps == PS_HIT);
-            tracing = produce_ray<COUNTERS, DIFFUSE, TABS>(sv, rv, tab, P, h, c, pr, focal_cache, kBlock);
+            tracing = produce_ray<COUNTERS, DIFFUSE, TABS, true>(sv, rv, tab, P, h, c, pr, focal_cache, kBlock, spp_u);
             if (tracing) {
                 begin_ray<COUNTERS, TABS, kLdsStack, kBlock>(sv, tab, P, T, h, c, pr, lds_stack, spill, tid);
                 if (COUNTERS) c.rays++;
@@ -1377,7 +1386,7 @@ __device__ __forceinline__ void fill_tab(const SceneView &sv, float4 *lds_tab) {
     __syncthreads();
 }
 
-template <bool COUNTERS, bool DIFFUSE, bool TABS>
+template <bool COUNTERS, bool DIFFUSE, bool TABS, bool IMPLICIT = false>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(ORT_WAVES_PER_EU, ORT_WAVES_PER_EU)))
 pt_persistent(SceneView sv, RenderHot rv) {
     __shared__ uint32_t lds_stack[kLdsStack * kBlock];
@@ -1390,7 +1399,7 @@ pt_persistent(SceneView sv, RenderHot rv) {
         if (threadIdx.x < 4) g_lds_prof[96 + threadIdx.x] = __builtin_amdgcn_s_memtime();
         __syncthreads();
     }
-    pt_lane<COUNTERS, DIFFUSE, TABS>(sv, rv, lds_tab, lds_stack, lds_focal, (int)threadIdx.x, blockIdx.x * (uint32_t)kBlock + threadIdx.x, prof);
+    pt_lane<COUNTERS, DIFFUSE, TABS, IMPLICIT>(sv, rv, lds_tab, lds_stack, lds_focal, (int)threadIdx.x, blockIdx.x * (uint32_t)kBlock + threadIdx.x, prof);
     if (prof) {
         __syncthreads();
         if (threadIdx.x < 96 && g_lds_prof[threadIdx.x]) atomicAdd(sv.util + threadIdx.x, g_lds_prof[threadIdx.x]);
@@ -1968,8 +1977,11 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
         } else
         if (counters && diffuse && want_util) { if (tabs) ORT_LAUNCH(true, true, true); else ORT_LAUNCH(true, true, false); }
         else if (counters) { if (tabs) ORT_LAUNCH(true, false, true); else ORT_LAUNCH(true, false, false); }
-        else if (diffuse) { if (tabs) ORT_LAUNCH(false, true, true); else ORT_LAUNCH(false, true, false); }
-        else { if (tabs) ORT_LAUNCH(false, false, true); else ORT_LAUNCH(false, false, false); }
+        /* IMPLICIT job spaces (PIXEL / CHUNK policies): the variant whose lanes carry no job rect / count / index */
+        else if (diffuse) { if (tabs && rv.mode != JOBS_EXPLICIT) hipLaunchKernelGGL((pt_persistent<false, true, true, true>), dim3(grid), dim3(kBlock), 0, stream, sv, hot);
+                            else if (tabs) ORT_LAUNCH(false, true, true); else ORT_LAUNCH(false, true, false); }
+        else { if (tabs && rv.mode != JOBS_EXPLICIT) hipLaunchKernelGGL((pt_persistent<false, false, true, true>), dim3(grid), dim3(kBlock), 0, stream, sv, hot);
+               else if (tabs) ORT_LAUNCH(false, false, true); else ORT_LAUNCH(false, false, false); }
 #undef ORT_LAUNCH
         ORT_HIP(hipGetLastError());
     }
