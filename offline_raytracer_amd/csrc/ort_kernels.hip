@@ -135,6 +135,7 @@ struct RenderView {
     uint32_t capL, capR;
     uint32_t long_min;   /* start a traversal phase on parked rays when tracing lanes + parked rays reach this */
     uint32_t long_refill; /* within such a phase, take more parked rays when fewer lanes than this are tracing */
+    uint32_t park_min;   /* stragglers are parked only when there are at least this many of them (fewer: they idle through one shading pass, cheaper than an exchange step) */
     uint32_t inflight_cap; /* a lane without a path starts a new job only while the wave holds fewer parked paths than this
                               (every parked path is a job in progress: the more a wave holds, the longer its tail) */
 };
@@ -1245,7 +1246,7 @@ ORT_D void pt_lane_x(const SceneView &sv, const RenderHot &rv, const float4 *tab
             if (n_tr == 0u && __ballot(take) == 0ull) long_phase = false;
         } else {
             /* park the stragglers (their stack tail must be in LDS), then hand the free lanes parked finished paths */
-            const bool can_park = tracing && T.sp <= kLdsStack;
+            const bool can_park = tracing && T.sp <= kLdsStack && n_tr >= rv.c->park_min;
             const unsigned long long m_park = __ballot(can_park);
             const uint32_t prank = lane_rank(m_park);
             const bool park = can_park && ltop + prank < L.cap;
@@ -1948,6 +1949,7 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
             rv.long_min = (e = getenv("ORT_LONG_MIN")) ? (uint32_t)atoi(e) : 64u;
             rv.long_refill = (e = getenv("ORT_LONG_REFILL")) ? (uint32_t)atoi(e) : 32u;
             rv.inflight_cap = (e = getenv("ORT_INFLIGHT_CAP")) ? (uint32_t)atoi(e) : 64u;
+            rv.park_min = (e = getenv("ORT_PARK_MIN")) ? (uint32_t)atoi(e) : 1u;
             if (rv.long_min < 1u) rv.long_min = 1u;
             if (rv.long_min > rv.capL) rv.long_min = rv.capL;
             if (rv.long_refill > 64u) rv.long_refill = 64u;
