@@ -114,12 +114,33 @@ def build_library():
     subprocess.check_call(["make", "-s", "-C", CSRC_DIR])
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  libort.so needs libamdhip64.so.7 and finds the system's (/opt/rocm); PyTorch ships
+    its own copy under torch/lib and asks for it by file name, so if libort.so is loaded BEFORE torch the process ends
+    up with two runtimes and the second one to initialise finds "no ROCm-capable device".  Loading torch's copy first
+    (without importing torch) makes both resolve to the same library whatever the import order.  Only where torch is
+    installed and only for this Python binding; the C++ driver uses the system runtime.  ORT_SYSTEM_HIP=1 opts out."""
+    if os.environ.get("ORT_SYSTEM_HIP") == "1":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(path):
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except Exception:  # noqa: BLE001 -- best effort: without it the import order decides, as before
+        pass
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise OrtError(ERR_STATE, "libort.so is not built (run offline_raytracer_amd.api.build_library() or "
                                       "make -C offline_raytracer_amd/csrc); there is no fallback implementation")
+        _share_hip_runtime_with_torch()
         L = C.CDLL(LIB_PATH)
         L.ort_last_error.restype = C.c_char_p
         L.ort_scene_load_scn.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p)]

@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -48,10 +49,15 @@ Rccl g_rccl;
 
 int load_rccl(std::string *err) {
     if (g_rccl.lib) return ORT_OK;
-    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    /* If the process already has an RCCL (a host program that links it; PyTorch ships its own librccl.so), use THAT
+       one -- two RCCL builds in one process is asking for trouble -- otherwise load the system's.  RTLD_LOCAL: nothing
+       else in the process should start resolving nccl* symbols against a library we pulled in. */
+    const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
     void *h = nullptr;
     for (const char *n : names)
-        if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+        if ((h = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD))) break;
+    for (const char *n : names)
+        if (!h && (h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
     if (!h) { *err = std::string("cannot load librccl.so: ") + dlerror(); return ORT_ERR_UNSUPPORTED; }
     Rccl r;
     r.lib = h;
@@ -166,14 +172,22 @@ int comm_create(const void *id, int rank, int world, int device, Comm **out, std
     if (world < 1 || rank < 0 || rank >= world) { *err = "bad rank / world"; return ORT_ERR_INVALID; }
     Comm *c = new Comm();
     c->rank = rank; c->world = world; c->device = device;
-    if (world > 1) {
+    /* ORT_COMM_FORCE_RCCL (tests on a one-GPU box): a world of one still gets a real communicator, and its gather
+       sends the packed blocks to itself through RCCL -- the same entry points, argument lists and stream semantics as
+       the N-rank path, exercised on hardware */
+    const bool force = world == 1 && getenv("ORT_COMM_FORCE_RCCL") != nullptr;
+    if (world > 1 || force) {
         int rc = load_rccl(err);
         if (rc) { delete c; return rc; }
-        if (!id) { delete c; *err = "null unique id"; return ORT_ERR_INVALID; }
+        if (!id && !force) { delete c; *err = "null unique id"; return ORT_ERR_INVALID; }
         hipError_t e = hipSetDevice(device);
         if (e != hipSuccess) { delete c; *err = std::string("hipSetDevice: ") + hipGetErrorString(e); return ORT_ERR_HIP; }
         ncclUniqueId u;
-        memcpy(&u, id, sizeof(u));
+        if (id) memcpy(&u, id, sizeof(u));
+        else {
+            ncclResult_t r0 = g_rccl.GetUniqueId(&u);
+            if (r0 != ncclSuccess) { *err = std::string("ncclGetUniqueId: ") + g_rccl.GetErrorString(r0); delete c; return ORT_ERR_HIP; }
+        }
         ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, u, rank);
         if (r != ncclSuccess) { *err = std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r); delete c; return ORT_ERR_HIP; }
     }
@@ -246,8 +260,21 @@ int gather_framebuffer(Comm *c, const void *d_packed, void *d_full, int32_t w, i
     hipStream_t stream = (hipStream_t)stream_v;
     ORT_HIPC(hipSetDevice(c->device));
     if (c->rank == 0 && !d_full) { *err = "rank 0 needs the full framebuffer"; return ORT_ERR_INVALID; }
-    if (c->world == 1) return unpack_on_device(d_packed, w, h, 0, 1, d_full, stream, err);
     int rc;
+    if (c->world == 1 && c->comm) { /* forced communicator of one: the blocks travel rank 0 -> rank 0 through RCCL */
+        const size_t n = (size_t)blocks_of(w, h, 0, 1) * 192u;
+        if ((rc = ensure_staging(c, n * 4u + 16u, err))) return rc;
+        ORT_NCCL(g_rccl.GroupStart());
+        ncclResult_t rs = g_rccl.Send(d_packed, n, ncclFloat, 0, c->comm, stream);
+        ncclResult_t rr = g_rccl.Recv(c->staging, n, ncclFloat, 0, c->comm, stream);
+        ncclResult_t ge = g_rccl.GroupEnd();
+        if (rs != ncclSuccess || rr != ncclSuccess || ge != ncclSuccess) {
+            *err = std::string("RCCL self transfer: ") + g_rccl.GetErrorString(rs != ncclSuccess ? rs : rr != ncclSuccess ? rr : ge);
+            return ORT_ERR_HIP;
+        }
+        return unpack_on_device(c->staging, w, h, 0, 1, d_full, stream, err);
+    }
+    if (c->world == 1) return unpack_on_device(d_packed, w, h, 0, 1, d_full, stream, err);
     if (c->rank == 0) {
         const size_t slot = (size_t)blocks_of(w, h, 0, (uint32_t)c->world) * 768u;
         if ((rc = ensure_staging(c, slot * (size_t)(c->world - 1), err))) return rc;

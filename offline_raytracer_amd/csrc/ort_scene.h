@@ -47,7 +47,10 @@ constexpr uint32_t MAX_LEAF_PRIMS = 16;
    (and refuses a tree that exceeds it), ort_kernels.hip static_asserts that its smallest stack (the re-traversal of
    resolve_hit: LDS entries minus the four it borrows, plus the scratch tail) holds it */
 constexpr uint32_t kTreeDepthBudget = 60;
-constexpr uint32_t kTreeletNodes = 32; /* the breadth-first top of the fast tree has indices [0, 32): kept in LDS by the kernel */
+#ifndef ORT_TREELET_NODES
+#define ORT_TREELET_NODES 32
+#endif
+constexpr uint32_t kTreeletNodes = ORT_TREELET_NODES; /* the breadth-first top of the fast tree has indices [0, 32): kept in LDS by the kernel */
 
 inline uint32_t make_leaf(uint32_t kind, uint32_t first, uint32_t count) {
     return LEAF_BIT | (kind << 28) | ((count - 1u) << 24) | (first & 0x00ffffffu);

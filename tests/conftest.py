@@ -66,7 +66,10 @@ def gpu_scene(api, load_scene):
         s = load_scene(name)
         if s.device is None:
             if api.device_count() < 1:
-                pytest.fail("GPU test on a machine without a HIP device (the render path has no CPU fallback)")
+                n = api.C.c_int(0)
+                rc = api.lib().ort_device_count(api.C.byref(n))
+                pytest.fail("GPU test on a machine without a HIP device (the render path has no CPU fallback): "
+                            "ort_device_count rc %d, %r" % (rc, api.lib().ort_last_error()))
             s.upload(0)
         return s
     return _load

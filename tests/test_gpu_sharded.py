@@ -70,6 +70,26 @@ def test_sharded_renderer_world_one_goes_through_the_c_gather(api, gpu_scene):
     assert_bits_equal(full.cpu().numpy(), ref, "ShardedRenderer world=1")
 
 
+def test_gather_through_a_real_rccl_communicator(api, gpu_scene, monkeypatch):
+    """ORT_COMM_FORCE_RCCL: a world of one gets a real ncclComm (ncclGetUniqueId + ncclCommInitRank through the
+    dlopen'd entry points) and the gather moves the packed blocks rank 0 -> rank 0 with the grouped ncclSend / ncclRecv
+    of the N-rank path, on the caller's stream, before the un-permute kernel: everything of the collective that can run
+    on one GPU"""
+    torch = _torch()
+    from offline_raytracer_amd import dist as odist
+    monkeypatch.setenv("ORT_COMM_FORCE_RCCL", "1")
+    scene = gpu_scene("c4_dwarf_room")
+    w, h, spp, seed = 203, 117, 4, 3
+    sr = odist.ShardedRenderer(scene, w, h, 0, 1, 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    sr.render(sr.params(spp, seed, "chunk", chunk=2), stream=stream, want_stats=True)
+    full = sr.gather(stream=stream)
+    torch.cuda.synchronize()
+    ref, _ = scene.render(w, h, spp, seed, "chunk", chunk=2)
+    assert_bits_equal(full.cpu().numpy(), ref, "gather through RCCL, world = 1")
+    sr.comm.close()
+
+
 def test_per_rank_workspace_at_the_stress_config(api):
     """BASELINE.json configs[4] on 8 GPUs: 3840x2160, 4096 spp in 64-sample jobs -- a rank keeps 1/8 of the partial
     planes (round 1: full frames, 6.4 GB per rank)"""
