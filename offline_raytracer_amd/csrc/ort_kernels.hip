@@ -1861,11 +1861,13 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
     rv.x0 = p->x0; rv.y0 = p->y0; rv.x1 = p->x1; rv.y1 = p->y1;
     rv.seed = p->seed; rv.spp = p->spp; rv.chunk = p->chunk; rv.rr = p->rr;
     rv.out = out;
+    bool cache_resident_tree = true;
     {
         /* tuning knobs; results do not depend on them.  Defaults tuned on MI355X (profiles/r01_tuning.md)
            separately for trees that stay in L2 and trees that do not */
         const size_t fast_tree_bytes = scene->tree.nodes.size() * sizeof(DevNode) + scene->tree.tris.size() * sizeof(DevTri);
         const bool cache_resident = fast_tree_bytes <= (size_t)(16u << 20);
+        cache_resident_tree = cache_resident;
         const char *e = getenv("ORT_REFILL_BELOW");
         rv.refill_below = e ? atoi(e) : (cache_resident ? 12 : 32);
         if (rv.refill_below < 1) rv.refill_below = 1;
@@ -1940,7 +1942,9 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
            launches of at least 24 jobs per lane -- every parked path is a job in progress, so a wave's tail grows with
            what it has parked, which short launches and 8-way shards cannot amortise.  ORT_EXCHANGE=0 / 1 forces it. */
         const char *xenv = getenv("ORT_EXCHANGE");
-        const bool worth_it = diffuse && rv.job_count >= 24ull * (unsigned long long)grid * kBlock;
+        /* ... and not for trees that leave the L2 (the 1M-triangle scene: 875 vs 930 Mpaths/s): there the stash traffic
+           competes with the tree for the cache */
+        const bool worth_it = diffuse && cache_resident_tree && rv.job_count >= 24ull * (unsigned long long)grid * kBlock;
         exch = tabs && rv.mode != JOBS_EXPLICIT && (xenv ? atoi(xenv) != 0 : worth_it) && (!counters || (want_util && diffuse));
         if (exch && !getenv("ORT_REFILL_BELOW")) rv.refill_below = 16; /* stragglers park instead of idling: leave the loop a little earlier */
         if (exch) {
