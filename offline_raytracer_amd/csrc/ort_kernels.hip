@@ -284,6 +284,10 @@ struct Prof { unsigned long long t = 0; bool on = false; };
 #define ORT_DESCEND_SHIFT 2
 #endif
 
+/* branch-frequency hints: the register allocator weighs spill code by block frequency, and this kernel lives at its
+   128-register cap -- the rare paths (ties, phantoms, re-traversals, the exact fallback, deep stacks) should carry the
+   spills, not the code every ray runs */
+#define ORT_RARE(x) __builtin_expect(!!(x), 0)
 constexpr uint32_t kNoPrim = 0xffffffffu;
 constexpr uint32_t kTraversalDone = 0xffffffffu; /* == EMPTY_CHILD: a leaf word no tree contains */
 
@@ -326,14 +330,14 @@ ORT_D void test_prim(const SceneView &sv, uint32_t kind, uint32_t slot, V3 org, 
         if (COUNTERS) c_analytic++;
         t = hit_cylinder(mk(a.x, a.y, a.z), a.w, mk(b.x, b.y, b.z), mk(b.w, c.x, c.y), mk(c.z, c.w, d.x), d.y, org, dir, n);
     }
-    if (!EXACT_ORDER && tangent) {
+    if (ORT_RARE(!EXACT_ORDER && tangent)) {
         /* a phantom hit outside its box: whether the reference sees it depends on its visiting
            order, so it never competes here; the caller re-casts the ray exactly if it could win */
         phantom_t = fminf(phantom_t, t);
         return;
     }
     bool take = (t >= kHitTMin && t < best_t);
-    if (!EXACT_ORDER && t == best_t && t >= kHitTMin && hit_prim != kNoPrim) {
+    if (ORT_RARE(!EXACT_ORDER && t == best_t && t >= kHitTMin && hit_prim != kNoPrim)) {
         /* bit-equal distance (e.g. the shared diagonal of a fan-triangulated quad): the reference
            keeps whichever it tested first */
         take = prim_order(sv, kind, slot) < prim_order(sv, hit_prim >> 28, hit_prim & 0x00ffffffu);
@@ -423,7 +427,7 @@ ORT_D int chain_verdict(const SceneView &sv, uint32_t prim, V3 org, V3 inv_d, fl
     if (len == 0u) return CH_ADMIT;
     const bool finite = (om_f32_bits(inv_d.x) & 0x7fffffffu) < 0x7f800000u && (om_f32_bits(inv_d.y) & 0x7fffffffu) < 0x7f800000u &&
                         (om_f32_bits(inv_d.z) & 0x7fffffffu) < 0x7f800000u;
-    if (!(word & kChainNested) || !finite) return chain_verdict_full(sv, first, len, org, inv_d, t_hit, t_other, gap);
+    if (ORT_RARE(!(word & kChainNested) || !finite)) return chain_verdict_full(sv, first, len, org, inv_d, t_hit, t_other, gap);
     const float4 dlo = sv.chain_boxes[2u * first], dhi = sv.chain_boxes[2u * first + 1u];
     float4 jlo = dlo, jhi = dhi;
     bool found = false;
@@ -604,7 +608,7 @@ ORT_D void prologue_tests(const SceneView &sv, const float4 *tab, V3 org, V3 dir
 template <bool COUNTERS>
 ORT_D void recast_exactly(const SceneView &sv, bool need, V3 org, V3 dir, V3 inv_d, uint32_t lane_id, HitState &h, Counters &c) {
     unsigned long long pending = ORT_BALLOT(need);
-    while (pending) {
+    while (ORT_RARE(pending != 0ull)) {
         const int leader = ORT_FFS64(pending) - 1;
         if (ORT_LANE() == leader) {
             ORT_COUNT(sv.cold->fallback_counters, 1ull); /* straight to memory, no register kept across the loop */
@@ -890,7 +894,7 @@ ORT_D void visit_node(float4 a, float4 b, float4 cc, float4 d, V3 org, V3 inv_d,
         bool swap = n1 < n0;
         uint32_t farc = swap ? c0 : c1;
         cur = swap ? c1 : c0;
-        if (sp < LDS_ENTRIES) lds_stack[sp * BLOCK + tid] = farc;
+        if (!ORT_RARE(sp >= LDS_ENTRIES)) lds_stack[sp * BLOCK + tid] = farc;
         else spill[sp - LDS_ENTRIES] = farc;
         sp++;
     } else if (h0) {
@@ -1024,12 +1028,12 @@ ORT_D void resolve_hit(const SceneView &sv, const float4 *tab, V3 org, V3 dir, V
                        uint32_t *lds_stack, uint32_t *spill, int tid) {
     bool recast = sv.force_fallback_mask != 0xffffffffu && (om_f32_bits(dir.x) & sv.force_fallback_mask) == 0u;
     if (!recast) {
-        if (h.phantom_t <= h.best_t) {
+        if (ORT_RARE(h.phantom_t <= h.best_t)) {
             recast = true;
         } else if (h.hit_prim != kNoPrim) {
             float gap = 0.0f;
             const int verdict = chain_verdict(sv, h.hit_prim, org, inv_d, h.best_t, fminf(h.runner_t, h.phantom_t), gap);
-            if (verdict != CH_ADMIT) {
+            if (ORT_RARE(verdict != CH_ADMIT)) {
                 /* W waits in the lane's (idle) traversal-stack slots of LDS, not in registers */
                 const uint32_t w_prim = h.hit_prim;
                 uint32_t *save = lds_stack + tid;
