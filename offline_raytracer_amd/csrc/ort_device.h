@@ -236,25 +236,30 @@ ORT_D V3 sample_lobe(V3 N, float c, float phi) { return sample_lobe_n(normalize(
 /* sample_brdf (ray.cpp:1100-1161) in two halves around the evaluation of cos/sin(phi):
    draw: the three RNG draws, the lobe's cos(theta) and the azimuth phi = 2 pi e1 */
 struct BrdfDraw { float c, phi, choice; };
+/* DIFFUSE_SCENE: every material has pd_c = 1, so the other lobes are drawn only when the choice is exactly 1.0 -- a hint
+   for the register allocator (block frequencies), not a change of the code's meaning */
+template <bool DIFFUSE_SCENE = false>
 ORT_D BrdfDraw sample_brdf_draw(uint32_t &rng, float rough, const Mat &mt) {
     float e0 = rng_01(rng), e1 = rng_01(rng);
     BrdfDraw d;
     d.choice = rng_01(rng);
     d.phi = 2.0f * kPi * e1;
-    if (d.choice < mt.pd_c) d.c = __builtin_sqrtf(e0);                                                  /* ray.cpp:1123 */
+    const bool diffuse_lobe = d.choice < mt.pd_c;
+    if (DIFFUSE_SCENE ? __builtin_expect(diffuse_lobe, 1) : diffuse_lobe) d.c = __builtin_sqrtf(e0);      /* ray.cpp:1123 */
     else d.c = ort_cosf(ort_atan2f(rough * __builtin_sqrtf(e0), __builtin_sqrtf(1.0f - e0)));          /* ray.cpp:1128,1138 */
     return d;
 }
 /* finish: the direction from the lobe sample */
 /* NORMALIZED = false leaves ray.cpp:1158's final normalisation to the caller (the kernel shares it with the
    camera branch's) */
-template <bool NORMALIZED = true>
+template <bool NORMALIZED = true, bool DIFFUSE_SCENE = false>
 ORT_D V3 sample_brdf_finish(V3 N, V3 Nn, V3 wo, const Mat &mt, BrdfDraw d, float cos_phi, float sin_phi, bool &is_trans) {
     float pd_c = mt.pd_c, ps_c = mt.ps_c; /* per material, ray.cpp:1105-1113 */
     V3 wi;
     is_trans = false;
     V3 m = sample_lobe_n(Nn, d.c, cos_phi, sin_phi); /* Nn = normalize(N): ray.cpp:1069 re-normalises N */
-    if (d.choice < pd_c) {
+    const bool diffuse_lobe = d.choice < pd_c;
+    if (DIFFUSE_SCENE ? __builtin_expect(diffuse_lobe, 1) : diffuse_lobe) {
         wi = m;
     } else {
         bool refract = !(d.choice >= pd_c && d.choice < pd_c + ps_c);

@@ -587,7 +587,7 @@ ORT_D void prologue_tests(const SceneView &sv, const float4 *tab, V3 org, V3 dir
     const float4 *pb = tab + kTabPro, *ps = pb + 2u * sv.pro_boxes, *pc = ps + sv.pro_spheres;
     /* boxes: when every lane's origin and 1/d are finite (all but a handful of rays), the slab test runs on the
        hardware's min / max (hit_aab_finite: same values); wave-uniform choice, so no lane waits for the other form */
-    if (ORT_BALLOT(!all_finite6(org, inv_d)) == 0ull) {
+    if (!ORT_RARE(ORT_BALLOT(!all_finite6(org, inv_d)) != 0ull)) {
         for (uint32_t i = 0; i < sv.pro_boxes; ++i)
             test_prim<COUNTERS, false, true, TABS>(sv, PRIM_BOX, i, org, dir, inv_d, h.best_t, h.hit_n, h.hit_prim, h.phantom_t, h.runner_t, c.tris, c.analytic, excl, pb + 2u * i);
     } else {
@@ -678,7 +678,7 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderHot &rv, const float4 *t
                 if (TABS) m = load_mat(tab + kTabMats, hit_mat);
                 else m = load_mat(sv.materials, hit_mat);
             }
-            if (!hit_mat) {
+            if (ORT_RARE(!hit_mat)) {
                 alive = false; /* bounce miss: ray.cpp:1418-1421; primary miss: undefined in the reference, defined: terminate */
             } else if (m.is_light) {
                 /* ray.cpp:1254-1259 (primary: unweighted, unchecked) / :1358-1371 (bounce: dropped if not finite) */
@@ -713,7 +713,7 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderHot &rv, const float4 *t
                     if (is_sphere) { rng_step(P.rng); rng_step(P.rng); rng_step(P.rng); rng_step(P.rng); }
                 }
                 ORT_UTIL(sv, 6, true);
-                draw = sample_brdf_draw(P.rng, kRoughness, m);
+                draw = sample_brdf_draw<DIFFUSE>(P.rng, kRoughness, m);
                 angle = draw.phi;
             } else {
                 P.sample++;
@@ -726,7 +726,7 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderHot &rv, const float4 *t
                Pixel write-back, next pixel / next job and the new camera ray all happen in this same
                pass, so the rest of the wave does not wait through a second trip round the loop. */
             const uint32_t job_spp = IMPLICIT ? spp_u : P.spp;
-            if (P.ps == PS_SAMPLE && P.sample == job_spp) {
+            if (ORT_RARE(P.ps == PS_SAMPLE && P.sample == job_spp)) { /* once per job */
                 /* ray.cpp:1428 */
                 V3 o = divs(P.color, (float)job_spp);
                 uint32_t px = P.pxy & 0xffffu, py = P.pxy >> 16;
@@ -746,7 +746,7 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderHot &rv, const float4 *t
                 }
                 }
             }
-            if (P.ps == PS_NEED_JOB) {
+            if (ORT_RARE(P.ps == PS_NEED_JOB)) {
                 unsigned long long j = ORT_NEXT_JOB(rv.c->next_job);
                 if (j >= rv.c->job_count) { P.ps = PS_DONE; break; }
                 if (!IMPLICIT && rv.mode == JOBS_EXPLICIT) {
@@ -785,7 +785,7 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderHot &rv, const float4 *t
                 }
                 P.ps = PS_PIXEL;
             }
-            if (P.ps == PS_PIXEL) {
+            if (ORT_RARE(P.ps == PS_PIXEL)) {
                 ORT_SIM_PIXEL_HOOK((int)(P.pxy & 0xffffu), (int)(P.pxy >> 16), P.rng);
                 P.color = mk(0, 0, 0); /* ray.cpp:1211 */
                 P.sample = 0;
@@ -795,7 +795,7 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderHot &rv, const float4 *t
                     focal_cache[0] = f.x; focal_cache[focal_stride] = f.y; focal_cache[2 * focal_stride] = f.z;
                 }
             }
-            if (P.sample == job_spp) continue; /* spp == 0: the reference's sample loop runs zero times */
+            if (ORT_RARE(P.sample == job_spp)) continue; /* spp == 0: the reference's sample loop runs zero times */
             /* ray.cpp:1215-1221: point on the focal plane through the pixel centre: a function of the pixel alone,
                read back from the per-lane cache or (wavefront mode) recomputed -- same expressions, same bits */
             focal = focal_cache ? mk(focal_cache[0], focal_cache[focal_stride], focal_cache[2 * focal_stride])
@@ -819,7 +819,7 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderHot &rv, const float4 *t
             const V3 unit1 = normalize(bounce ? n : sub(focal, ap));
             bool is_trans = false;
             V3 raw = unit1;
-            if (bounce) raw = sample_brdf_finish<false>(n, unit1, P.wo, m, draw, cs, sn, is_trans);
+            if (bounce) raw = sample_brdf_finish<false, true>(n, unit1, P.wo, m, draw, cs, sn, is_trans);
             const V3 unit2 = normalize(raw);
             if (bounce) {
                 if (is_trans) P.org = add(P.org, scale(2.0f * kEps, P.dir)); /* ray.cpp:1345-1348: dir is still the arriving direction */
@@ -1027,7 +1027,7 @@ template <bool COUNTERS, bool TABS, int LDS_ENTRIES, int BLOCK>
 ORT_D void resolve_hit(const SceneView &sv, const float4 *tab, V3 org, V3 dir, V3 inv_d, uint32_t lane_id, HitState &h, Counters &c, Prof &pr,
                        uint32_t *lds_stack, uint32_t *spill, int tid) {
     bool recast = sv.force_fallback_mask != 0xffffffffu && (om_f32_bits(dir.x) & sv.force_fallback_mask) == 0u;
-    if (!recast) {
+    if (!ORT_RARE(recast)) {
         if (ORT_RARE(h.phantom_t <= h.best_t)) {
             recast = true;
         } else if (h.hit_prim != kNoPrim) {
@@ -1204,7 +1204,7 @@ ORT_D void pt_lane_x(const SceneView &sv, const RenderHot &rv, const float4 *tab
            finish): lanes without a path take parked ones, finished rays first, and everything else carries on */
         const bool endgame = __ballot(P.ps == PS_DONE) != 0ull;
         bool long_phase = !endgame && ltop > 0u && (n_tr + ltop >= rv.c->long_min || drain);
-        if (endgame) {
+        if (ORT_RARE(endgame)) {
             const bool is_free = !tracing && P.ps != PS_HIT;
             const unsigned long long m_recv = __ballot(is_free);
             const uint32_t rrank = lane_rank(m_recv);
