@@ -51,7 +51,7 @@ ORT_D float rmin(float a, float b) { return (a < b) ? a : b; }                  
 ORT_D float rmax(float a, float b) { return (a > b) ? a : b; }                    /* types.h:50: NaN -> b */
 ORT_D V3 normalize(V3 a) {                                                        /* math.h:298-310 */
     float l = len(a);
-    if (!ceq(l, 0.0f)) return divs(a, l);
+    if (__builtin_expect(!ceq(l, 0.0f), 1)) return divs(a, l);
     return mk(0, 0, 0);
 }
 ORT_D bool isnan3(V3 v) { return (v.x != v.x) || (v.y != v.y) || (v.z != v.z); }
@@ -320,7 +320,7 @@ ORT_D float hit_sphere(V3 c, float rad, V3 o, V3 d, V3 &n, bool &tangent) {     
             ht = t;
             n = scale(1.0f, sub(add(o, scale(ht, d)), c));
         }
-    } else if (root < tol && root > -tol) {
+    } else if (__builtin_expect(root < tol && root > -tol, 0)) { /* tangent: rare */
         float t = (-b) / (2 * a);
         if (t > kHitTMin) {
             ht = t;

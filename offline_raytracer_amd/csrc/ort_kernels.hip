@@ -683,7 +683,7 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderHot &rv, const float4 *t
             } else if (m.is_light) {
                 /* ray.cpp:1254-1259 (primary: unweighted, unchecked) / :1358-1371 (bounce: dropped if not finite) */
                 V3 e = P.primary ? m.emit : had(P.weight, m.emit);
-                if (P.primary || (!isnan3(e) && !isinf3(e))) P.color = add(P.color, e);
+                if (__builtin_expect(P.primary || (!isnan3(e) && !isinf3(e)), 1)) P.color = add(P.color, e);
                 alive = false;
             } else {
                 if (P.primary) {
@@ -907,7 +907,7 @@ ORT_D void visit_node(float4 a, float4 b, float4 cc, float4 d, V3 org, V3 inv_d,
         sp--;
         /* two real loads behind a branch (the volatile keeps the compiler from merging them into one
            flat_load of a selected generic pointer): the LDS side becomes a plain ds_read */
-        if (sp < LDS_ENTRIES) cur = lds_stack[sp * BLOCK + tid];
+        if (!ORT_RARE(sp >= LDS_ENTRIES)) cur = lds_stack[sp * BLOCK + tid];
         else cur = ((volatile uint32_t *)spill)[sp - LDS_ENTRIES];
     }
 }
@@ -995,7 +995,7 @@ ORT_D bool traverse(const SceneView &sv, V3 org, V3 dir, Trav &T, HitState &h, u
                 sp--;
                 /* two real loads behind a branch (the volatile keeps the compiler from merging them into one
                    flat_load of a selected generic pointer): the LDS side becomes a plain ds_read */
-                if (sp < LDS_ENTRIES) cur = lds_stack[sp * BLOCK + tid];
+                if (!ORT_RARE(sp >= LDS_ENTRIES)) cur = lds_stack[sp * BLOCK + tid];
                 else cur = ((volatile uint32_t *)spill)[sp - LDS_ENTRIES];
             }
             ORT_PHASE(pr, sv, 6, true);
