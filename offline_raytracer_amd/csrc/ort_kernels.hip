@@ -284,10 +284,13 @@ struct Prof { unsigned long long t = 0; bool on = false; };
 #define ORT_DESCEND_SHIFT 2
 #endif
 
-/* branch-frequency hints: the register allocator weighs spill code by block frequency, and this kernel lives at its
-   128-register cap -- the rare paths (ties, phantoms, re-traversals, the exact fallback, deep stacks) should carry the
-   spills, not the code every ray runs */
-#define ORT_RARE(x) __builtin_expect(!!(x), 0)
+/* Branch-frequency hints on the exactness machinery of resolve_hit (chain walk of odd chains, phantom hits, re-traversals,
+   the exact fallback): the register allocator weighs spill code by block frequency and this kernel lives at its
+   128-register cap, so telling it that these paths are rare moves the spills there: +4.4 % on the bunny room.  HINT is a
+   template parameter because the same hints cost the 1M-triangle scene 10 % (its launch is bound by what the L2 can take,
+   scratch traffic included: profiles/r02_tuning.md); hints on ties, deep stacks and the once-per-job blocks were neutral on
+   the one and harmful on the other and are not kept. */
+#define ORT_RARE(x) (HINT ? __builtin_expect(!!(x), 0) : !!(x))
 constexpr uint32_t kNoPrim = 0xffffffffu;
 constexpr uint32_t kTraversalDone = 0xffffffffu; /* == EMPTY_CHILD: a leaf word no tree contains */
 
@@ -330,14 +333,14 @@ ORT_D void test_prim(const SceneView &sv, uint32_t kind, uint32_t slot, V3 org, 
         if (COUNTERS) c_analytic++;
         t = hit_cylinder(mk(a.x, a.y, a.z), a.w, mk(b.x, b.y, b.z), mk(b.w, c.x, c.y), mk(c.z, c.w, d.x), d.y, org, dir, n);
     }
-    if (ORT_RARE(!EXACT_ORDER && tangent)) {
+    if (!EXACT_ORDER && tangent) {
         /* a phantom hit outside its box: whether the reference sees it depends on its visiting
            order, so it never competes here; the caller re-casts the ray exactly if it could win */
         phantom_t = fminf(phantom_t, t);
         return;
     }
     bool take = (t >= kHitTMin && t < best_t);
-    if (ORT_RARE(!EXACT_ORDER && t == best_t && t >= kHitTMin && hit_prim != kNoPrim)) {
+    if (!EXACT_ORDER && t == best_t && t >= kHitTMin && hit_prim != kNoPrim) {
         /* bit-equal distance (e.g. the shared diagonal of a fan-triangulated quad): the reference
            keeps whichever it tested first */
         take = prim_order(sv, kind, slot) < prim_order(sv, hit_prim >> 28, hit_prim & 0x00ffffffu);
@@ -417,6 +420,7 @@ constexpr uint32_t kChainNested = 0x08000000u;
 #if defined(ORT_HOST_SIM) && defined(ORT_CHAIN_CROSSCHECK)
 static unsigned long long g_chain_crosschecks = 0;
 #endif
+template <bool HINT>
 ORT_D int chain_verdict(const SceneView &sv, uint32_t prim, V3 org, V3 inv_d, float t_hit, float t_other, float &gap) {
     uint32_t kind = prim >> 28, slot = prim & 0x00ffffffu;
     uint32_t word = (kind == PRIM_TRI) ? sv.tri_chain[slot]
@@ -587,7 +591,7 @@ ORT_D void prologue_tests(const SceneView &sv, const float4 *tab, V3 org, V3 dir
     const float4 *pb = tab + kTabPro, *ps = pb + 2u * sv.pro_boxes, *pc = ps + sv.pro_spheres;
     /* boxes: when every lane's origin and 1/d are finite (all but a handful of rays), the slab test runs on the
        hardware's min / max (hit_aab_finite: same values); wave-uniform choice, so no lane waits for the other form */
-    if (!ORT_RARE(ORT_BALLOT(!all_finite6(org, inv_d)) != 0ull)) {
+    if (ORT_BALLOT(!all_finite6(org, inv_d)) == 0ull) {
         for (uint32_t i = 0; i < sv.pro_boxes; ++i)
             test_prim<COUNTERS, false, true, TABS>(sv, PRIM_BOX, i, org, dir, inv_d, h.best_t, h.hit_n, h.hit_prim, h.phantom_t, h.runner_t, c.tris, c.analytic, excl, pb + 2u * i);
     } else {
@@ -605,7 +609,7 @@ ORT_D void prologue_tests(const SceneView &sv, const float4 *tab, V3 org, V3 dir
    holding or waiting for a queue of the pool: a waiting lane can only wait for holders in other waves, which
    are running, never for a lane of its own wave parked at a reconvergence point.  The fences order the queue's
    contents across holders on different XCDs (each XCD has its own L2). */
-template <bool COUNTERS>
+template <bool COUNTERS, bool HINT>
 ORT_D void recast_exactly(const SceneView &sv, bool need, V3 org, V3 dir, V3 inv_d, uint32_t lane_id, HitState &h, Counters &c) {
     unsigned long long pending = ORT_BALLOT(need);
     while (ORT_RARE(pending != 0ull)) {
@@ -678,12 +682,12 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderHot &rv, const float4 *t
                 if (TABS) m = load_mat(tab + kTabMats, hit_mat);
                 else m = load_mat(sv.materials, hit_mat);
             }
-            if (ORT_RARE(!hit_mat)) {
+            if (!hit_mat) {
                 alive = false; /* bounce miss: ray.cpp:1418-1421; primary miss: undefined in the reference, defined: terminate */
             } else if (m.is_light) {
                 /* ray.cpp:1254-1259 (primary: unweighted, unchecked) / :1358-1371 (bounce: dropped if not finite) */
                 V3 e = P.primary ? m.emit : had(P.weight, m.emit);
-                if (__builtin_expect(P.primary || (!isnan3(e) && !isinf3(e)), 1)) P.color = add(P.color, e);
+                if (P.primary || (!isnan3(e) && !isinf3(e))) P.color = add(P.color, e);
                 alive = false;
             } else {
                 if (P.primary) {
@@ -726,7 +730,7 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderHot &rv, const float4 *t
                Pixel write-back, next pixel / next job and the new camera ray all happen in this same
                pass, so the rest of the wave does not wait through a second trip round the loop. */
             const uint32_t job_spp = IMPLICIT ? spp_u : P.spp;
-            if (ORT_RARE(P.ps == PS_SAMPLE && P.sample == job_spp)) { /* once per job */
+            if (P.ps == PS_SAMPLE && P.sample == job_spp) {
                 /* ray.cpp:1428 */
                 V3 o = divs(P.color, (float)job_spp);
                 uint32_t px = P.pxy & 0xffffu, py = P.pxy >> 16;
@@ -746,7 +750,7 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderHot &rv, const float4 *t
                 }
                 }
             }
-            if (ORT_RARE(P.ps == PS_NEED_JOB)) {
+            if (P.ps == PS_NEED_JOB) {
                 unsigned long long j = ORT_NEXT_JOB(rv.c->next_job);
                 if (j >= rv.c->job_count) { P.ps = PS_DONE; break; }
                 if (!IMPLICIT && rv.mode == JOBS_EXPLICIT) {
@@ -785,7 +789,7 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderHot &rv, const float4 *t
                 }
                 P.ps = PS_PIXEL;
             }
-            if (ORT_RARE(P.ps == PS_PIXEL)) {
+            if (P.ps == PS_PIXEL) {
                 ORT_SIM_PIXEL_HOOK((int)(P.pxy & 0xffffu), (int)(P.pxy >> 16), P.rng);
                 P.color = mk(0, 0, 0); /* ray.cpp:1211 */
                 P.sample = 0;
@@ -795,7 +799,7 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderHot &rv, const float4 *t
                     focal_cache[0] = f.x; focal_cache[focal_stride] = f.y; focal_cache[2 * focal_stride] = f.z;
                 }
             }
-            if (ORT_RARE(P.sample == job_spp)) continue; /* spp == 0: the reference's sample loop runs zero times */
+            if (P.sample == job_spp) continue; /* spp == 0: the reference's sample loop runs zero times */
             /* ray.cpp:1215-1221: point on the focal plane through the pixel centre: a function of the pixel alone,
                read back from the per-lane cache or (wavefront mode) recomputed -- same expressions, same bits */
             focal = focal_cache ? mk(focal_cache[0], focal_cache[focal_stride], focal_cache[2 * focal_stride])
@@ -894,7 +898,7 @@ ORT_D void visit_node(float4 a, float4 b, float4 cc, float4 d, V3 org, V3 inv_d,
         bool swap = n1 < n0;
         uint32_t farc = swap ? c0 : c1;
         cur = swap ? c1 : c0;
-        if (!ORT_RARE(sp >= LDS_ENTRIES)) lds_stack[sp * BLOCK + tid] = farc;
+        if (sp < LDS_ENTRIES) lds_stack[sp * BLOCK + tid] = farc;
         else spill[sp - LDS_ENTRIES] = farc;
         sp++;
     } else if (h0) {
@@ -907,7 +911,7 @@ ORT_D void visit_node(float4 a, float4 b, float4 cc, float4 d, V3 org, V3 inv_d,
         sp--;
         /* two real loads behind a branch (the volatile keeps the compiler from merging them into one
            flat_load of a selected generic pointer): the LDS side becomes a plain ds_read */
-        if (!ORT_RARE(sp >= LDS_ENTRIES)) cur = lds_stack[sp * BLOCK + tid];
+        if (sp < LDS_ENTRIES) cur = lds_stack[sp * BLOCK + tid];
         else cur = ((volatile uint32_t *)spill)[sp - LDS_ENTRIES];
     }
 }
@@ -995,7 +999,7 @@ ORT_D bool traverse(const SceneView &sv, V3 org, V3 dir, Trav &T, HitState &h, u
                 sp--;
                 /* two real loads behind a branch (the volatile keeps the compiler from merging them into one
                    flat_load of a selected generic pointer): the LDS side becomes a plain ds_read */
-                if (!ORT_RARE(sp >= LDS_ENTRIES)) cur = lds_stack[sp * BLOCK + tid];
+                if (sp < LDS_ENTRIES) cur = lds_stack[sp * BLOCK + tid];
                 else cur = ((volatile uint32_t *)spill)[sp - LDS_ENTRIES];
             }
             ORT_PHASE(pr, sv, 6, true);
@@ -1023,7 +1027,7 @@ ORT_D bool traverse(const SceneView &sv, V3 org, V3 dir, Trav &T, HitState &h, u
    The extra traversals run here, to completion, for the lanes that need them (1e-5 of the rays of the
    reference's scenes, 1e-2 with slanted cylinders) while the rest of the wave waits: the shape to ignore is
    a local of this rare branch, not a register carried through every ray's traversal. */
-template <bool COUNTERS, bool TABS, int LDS_ENTRIES, int BLOCK>
+template <bool COUNTERS, bool TABS, int LDS_ENTRIES, int BLOCK, bool HINT = true>
 ORT_D void resolve_hit(const SceneView &sv, const float4 *tab, V3 org, V3 dir, V3 inv_d, uint32_t lane_id, HitState &h, Counters &c, Prof &pr,
                        uint32_t *lds_stack, uint32_t *spill, int tid) {
     bool recast = sv.force_fallback_mask != 0xffffffffu && (om_f32_bits(dir.x) & sv.force_fallback_mask) == 0u;
@@ -1032,7 +1036,7 @@ ORT_D void resolve_hit(const SceneView &sv, const float4 *tab, V3 org, V3 dir, V
             recast = true;
         } else if (h.hit_prim != kNoPrim) {
             float gap = 0.0f;
-            const int verdict = chain_verdict(sv, h.hit_prim, org, inv_d, h.best_t, fminf(h.runner_t, h.phantom_t), gap);
+            const int verdict = chain_verdict<HINT>(sv, h.hit_prim, org, inv_d, h.best_t, fminf(h.runner_t, h.phantom_t), gap);
             if (ORT_RARE(verdict != CH_ADMIT)) {
                 /* W waits in the lane's (idle) traversal-stack slots of LDS, not in registers */
                 const uint32_t w_prim = h.hit_prim;
@@ -1060,12 +1064,12 @@ ORT_D void resolve_hit(const SceneView &sv, const float4 *tab, V3 org, V3 dir, V
                     recast = true;
                 } else if (h.hit_prim != kNoPrim) {
                     float gap2 = 0.0f;
-                    if (chain_verdict(sv, h.hit_prim, org, inv_d, h.best_t, fminf(h.runner_t, h.phantom_t), gap2) != CH_ADMIT) recast = true;
+                    if (chain_verdict<HINT>(sv, h.hit_prim, org, inv_d, h.best_t, fminf(h.runner_t, h.phantom_t), gap2) != CH_ADMIT) recast = true;
                 }
             }
         }
     }
-    recast_exactly<COUNTERS>(sv, recast, org, dir, inv_d, lane_id, h, c);
+    recast_exactly<COUNTERS, HINT>(sv, recast, org, dir, inv_d, lane_id, h, c);
 }
 
 ORT_D void flush_counters(const RenderHot &rv, const Counters &c, bool all) {
@@ -1079,7 +1083,7 @@ ORT_D void flush_counters(const RenderHot &rv, const Counters &c, bool all) {
 }
 
 /* persistent mode: one lane runs jobs until the job space is empty */
-template <bool COUNTERS, bool DIFFUSE = false, bool TABS = false, bool IMPLICIT = false>
+template <bool COUNTERS, bool DIFFUSE = false, bool TABS = false, bool IMPLICIT = false, bool HINT = true>
 ORT_D void pt_lane(const SceneView &sv, const RenderHot &rv, const float4 *tab, uint32_t *lds_stack, float *lds_focal, const int tid,
                    const uint32_t lane_id, bool prof_on = false) {
     uint32_t spill[kSpillStack];
@@ -1099,7 +1103,7 @@ ORT_D void pt_lane(const SceneView &sv, const RenderHot &rv, const float4 *tab, 
             ORT_UTIL(sv, 3, true);
             ORT_UTIL(sv, 4, P.ps == PS_HIT);
             ORT_PHASE(pr, sv, 7, true);
-            if (P.ps == PS_HIT) resolve_hit<COUNTERS, TABS, kLdsStack, kBlock>(sv, tab, P.org, P.dir, T.inv_d, lane_id, h, c, pr, lds_stack, spill, tid);
+            if (P.ps == PS_HIT) resolve_hit<COUNTERS, TABS, kLdsStack, kBlock, HINT>(sv, tab, P.org, P.dir, T.inv_d, lane_id, h, c, pr, lds_stack, spill, tid);
             ORT_PHASE(pr, sv, 0, P.ps == PS_HIT);
             tracing = produce_ray<COUNTERS, DIFFUSE, TABS, IMPLICIT>(sv, rv, tab, P, h, c, pr, lds_focal + tid, kBlock, spp_u);
             if (tracing) {
@@ -1204,7 +1208,7 @@ ORT_D void pt_lane_x(const SceneView &sv, const RenderHot &rv, const float4 *tab
            finish): lanes without a path take parked ones, finished rays first, and everything else carries on */
         const bool endgame = __ballot(P.ps == PS_DONE) != 0ull;
         bool long_phase = !endgame && ltop > 0u && (n_tr + ltop >= rv.c->long_min || drain);
-        if (ORT_RARE(endgame)) {
+        if (endgame) {
             const bool is_free = !tracing && P.ps != PS_HIT;
             const unsigned long long m_recv = __ballot(is_free);
             const uint32_t rrank = lane_rank(m_recv);
@@ -1391,7 +1395,7 @@ __device__ __forceinline__ void fill_tab(const SceneView &sv, float4 *lds_tab) {
     __syncthreads();
 }
 
-template <bool COUNTERS, bool DIFFUSE, bool TABS, bool IMPLICIT = false>
+template <bool COUNTERS, bool DIFFUSE, bool TABS, bool IMPLICIT = false, bool HINT = true>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(ORT_WAVES_PER_EU, ORT_WAVES_PER_EU)))
 pt_persistent(SceneView sv, RenderHot rv) {
     __shared__ uint32_t lds_stack[kLdsStack * kBlock];
@@ -1404,7 +1408,7 @@ pt_persistent(SceneView sv, RenderHot rv) {
         if (threadIdx.x < 4) g_lds_prof[96 + threadIdx.x] = __builtin_amdgcn_s_memtime();
         __syncthreads();
     }
-    pt_lane<COUNTERS, DIFFUSE, TABS, IMPLICIT>(sv, rv, lds_tab, lds_stack, lds_focal, (int)threadIdx.x, blockIdx.x * (uint32_t)kBlock + threadIdx.x, prof);
+    pt_lane<COUNTERS, DIFFUSE, TABS, IMPLICIT, HINT>(sv, rv, lds_tab, lds_stack, lds_focal, (int)threadIdx.x, blockIdx.x * (uint32_t)kBlock + threadIdx.x, prof);
     if (prof) {
         __syncthreads();
         if (threadIdx.x < 96 && g_lds_prof[threadIdx.x]) atomicAdd(sv.util + threadIdx.x, g_lds_prof[threadIdx.x]);
@@ -1988,6 +1992,10 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
         if (counters && diffuse && want_util) { if (tabs) ORT_LAUNCH(true, true, true); else ORT_LAUNCH(true, true, false); }
         else if (counters) { if (tabs) ORT_LAUNCH(true, false, true); else ORT_LAUNCH(true, false, false); }
         /* IMPLICIT job spaces (PIXEL / CHUNK policies): the variant whose lanes carry no job rect / count / index */
+        else if (tabs && rv.mode != JOBS_EXPLICIT && !cache_resident_tree) { /* trees that leave the L2: the variant without frequency hints (ORT_RARE) */
+            if (diffuse) hipLaunchKernelGGL((pt_persistent<false, true, true, true, false>), dim3(grid), dim3(kBlock), 0, stream, sv, hot);
+            else hipLaunchKernelGGL((pt_persistent<false, false, true, true, false>), dim3(grid), dim3(kBlock), 0, stream, sv, hot);
+        }
         else if (diffuse) { if (tabs && rv.mode != JOBS_EXPLICIT) hipLaunchKernelGGL((pt_persistent<false, true, true, true>), dim3(grid), dim3(kBlock), 0, stream, sv, hot);
                             else if (tabs) ORT_LAUNCH(false, true, true); else ORT_LAUNCH(false, true, false); }
         else { if (tabs && rv.mode != JOBS_EXPLICIT) hipLaunchKernelGGL((pt_persistent<false, false, true, true>), dim3(grid), dim3(kBlock), 0, stream, sv, hot);
