@@ -90,6 +90,25 @@ def test_gather_through_a_real_rccl_communicator(api, gpu_scene, monkeypatch):
     sr.comm.close()
 
 
+def test_packed_shards_with_the_ray_exchange(api, gpu_scene, monkeypatch):
+    """what bench.py steps on the headline: packed output + CHUNK partial planes + the ray exchange, here forced on for
+    two of three shards of a small frame; the union must be the plain one-GPU image"""
+    torch = _torch()
+    scene = gpu_scene("c3_bunny_room")
+    w, h, spp, chunk, seed, world = 320, 200, 16, 4, 99, 3
+    monkeypatch.setenv("ORT_EXCHANGE", "0")
+    whole, _ = scene.render(w, h, spp, seed, "chunk", chunk=chunk)
+    full = torch.zeros((h, w, 3), dtype=torch.float32, device="cuda")
+    for r in range(world):
+        monkeypatch.setenv("ORT_EXCHANGE", "1" if r != 1 else "0")
+        n = api.shard_block_count(w, h, r, world)
+        packed = torch.zeros((max(1, n), 64, 3), dtype=torch.float32, device="cuda")
+        scene.render_device(packed.data_ptr(), api.Scene.params(w, h, spp, seed, "chunk", chunk=chunk, shard=(r, world), packed=True), want_stats=True)
+        api.unpack_blocks_device(packed.data_ptr(), w, h, r, world, full.data_ptr())
+        torch.cuda.synchronize()
+    assert_bits_equal(full.cpu().numpy(), whole, "packed shards, exchange on")
+
+
 def test_per_rank_workspace_at_the_stress_config(api):
     """BASELINE.json configs[4] on 8 GPUs: 3840x2160, 4096 spp in 64-sample jobs -- a rank keeps 1/8 of the partial
     planes (round 1: full frames, 6.4 GB per rank)"""
