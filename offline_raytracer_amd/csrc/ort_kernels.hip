@@ -39,8 +39,10 @@ constexpr int kLdsStack = ORT_LDS_STACK; /* entries per lane in LDS: 24 * 256 * 
 #endif
 constexpr int kSpillStack = ORT_SPILL_STACK;  /* scratch tail */
 static_assert(kLdsStack - 4 + kSpillStack >= (int)kTreeDepthBudget, "the re-traversal of resolve_hit must hold a tree of kTreeDepthBudget levels");
-constexpr uint32_t kBfsPoolQueues = 256;      /* queues of the breadth-first fallback, shared by all lanes */
-constexpr size_t kBfsPoolBytes = 512u << 20; /* at most; a queue holds one entry per reference-tree node */
+constexpr uint32_t kBfsPoolQueues = 1024;     /* queues of the breadth-first fallback, shared by all lanes */
+constexpr size_t kBfsPoolBytes = 1024u << 20; /* at most; a queue holds one entry per reference-tree node */
+constexpr int kDiagFallback = 106;            /* fallback_counters = ctrl + 6: the diagnostics sit at ctrl[112..114] */
+constexpr uint32_t kBfsLockStride = 32;       /* u32 units: every lock word has a 128-byte line to itself */
 
 /* Small read-only tables every ray touches live in LDS, copied there once per workgroup: ~100 cycles of latency
    instead of a trip to L1 / L2 on the critical path of every ray (the kernel is latency-bound: DESIGN.md).
@@ -50,15 +52,11 @@ constexpr int kTabPro = 4;                       /* the analytic prologue's shap
 constexpr int kTabProCap = 40;
 constexpr int kTabLights = kTabPro + kTabProCap; /* light_is_sphere[64] as u32 */
 constexpr int kTabLightCap = 64;
-constexpr int kTabBoxMat = kTabLights + kTabLightCap / 4; /* material index of box / sphere / cylinder [100 each] as u32 */
-constexpr int kTabPrimMatCap = 100;
-constexpr int kTabSphereMat = kTabBoxMat + kTabPrimMatCap / 4;
-constexpr int kTabCylMat = kTabSphereMat + kTabPrimMatCap / 4;
-constexpr int kTabMats = kTabCylMat + kTabPrimMatCap / 4; /* DevMaterial records, 5 each */
+constexpr int kTabMats = kTabLights + kTabLightCap / 4; /* DevMaterial records, 5 each */
 constexpr int kTabMatCap = 48;
 constexpr int kTabTreelet = kTabMats + 5 * kTabMatCap; /* nodes [0, kTreeletNodes) of the fast tree, breadth-first top (ort_tree.cpp) */
-constexpr int kTabF4 = kTabTreelet + 4 * (int)kTreeletNodes; /* 503 float4 = 8048 B */
-enum : uint32_t { TAB_PRO = 1u, TAB_LIGHTS = 2u, TAB_PRIM_MATS = 4u, TAB_MATS = 8u };
+constexpr int kTabF4 = kTabTreelet + 4 * (int)kTreeletNodes; /* 428 float4 = 6848 B */
+enum : uint32_t { TAB_PRO = 1u, TAB_LIGHTS = 2u, TAB_MATS = 8u };
 
 #ifdef ORT_HOST_SIM
 #define ORT_CONSTANT_AS
@@ -80,21 +78,25 @@ struct SceneCold {
     uint32_t *bfs_pool;
     uint32_t *bfs_locks;
     uint32_t bfs_queue_cap, bfs_queue_count;
-    unsigned long long *fallback_counters; /* [0] rays re-cast exactly, [1] queue overflows (cannot happen: kept as a tripwire) */
+    unsigned long long *fallback_counters; /* [0] rays re-cast exactly, [1] queue overflows (cannot happen: kept as a tripwire);
+                                              diagnostics at [kDiagFallback]: octree nodes enqueued, rays traversed again, busy queues met */
 };
+
+/* chain: len << 28 | kChainNested | first pair of chain_boxes (ort_scene.h, RefTree); mat: material index */
+struct PrimInfo { uint32_t chain, mat; };
 
 struct SceneView {
     const float4 *tab_src;    /* kTabF4 float4, the image of the LDS tables */
     uint32_t tab_flags;
     const float4 *nodes;      /* 4 per node */
     const float4 *tris;       /* 3 per triangle: v0 e1 e2 n (12 floats) */
-    const uint32_t *tri_mat;
     const float4 *spheres;    /* 1 per sphere: c.xyz r */
-    const uint32_t *sphere_mat;
     const float4 *boxes;      /* 2 per box */
-    const uint32_t *box_mat;
     const float4 *cyls;       /* 4 per cylinder */
-    const uint32_t *cyl_mat;
+    /* what shading needs to know about a ray's winner: its visibility-chain word and its material index, ONE array
+       over all kinds (triangles first; info_index()) so that a lane can ask for both the moment its ray is finished */
+    const PrimInfo *prim_info;
+    uint32_t info_box, info_cyl, info_sphere; /* first entry of each analytic kind */
     const float4 *materials;  /* 5 per material (DevMaterial) */
     const uint32_t *light_is_sphere;
     uint32_t light_count;
@@ -102,11 +104,25 @@ struct SceneView {
     float cam[12];            /* p, x_axis, y_axis, z_axis */
     /* reference-compatible octree (ort_reftree.cpp): visibility chains */
     const float4 *chain_boxes; /* 2 per chain entry */
-    const uint32_t *tri_chain, *sphere_chain, *box_chain, *cyl_chain;
     const ORT_CONSTANT_AS SceneCold *cold; /* what only the rare paths read (ties, the exact fallback) */
     unsigned long long *util; /* diagnostics (ORT_DEBUG_UTIL=1, counters build): per-phase wave-iteration and active-lane sums */
     uint32_t force_fallback_mask; /* tests (ORT_DEBUG_FORCE_FALLBACK): also re-cast rays with (bits(dir.x) & mask) == 0; ~0u = off */
 };
+
+/* host: the PrimInfo array of a committed scene, triangles | boxes | cylinders | spheres */
+inline void build_prim_info(const Tree &t, const RefTree &rt, std::vector<PrimInfo> &out, uint32_t &info_box, uint32_t &info_cyl, uint32_t &info_sphere) {
+    info_box = (uint32_t)t.tri_mat.size();
+    info_cyl = info_box + (uint32_t)t.box_mat.size();
+    info_sphere = info_cyl + (uint32_t)t.cyl_mat.size();
+    out.assign((size_t)info_sphere + t.sphere_mat.size(), PrimInfo{0u, 0u});
+    auto fill = [&out](uint32_t base, const std::vector<uint32_t> &chain, const std::vector<uint32_t> &mat) {
+        for (size_t i = 0; i < mat.size(); ++i) out[base + i] = PrimInfo{i < chain.size() ? chain[i] : 0u, mat[i]};
+    };
+    fill(0u, rt.tri_chain, t.tri_mat);
+    fill(info_box, rt.box_chain, t.box_mat);
+    fill(info_cyl, rt.cyl_chain, t.cyl_mat);
+    fill(info_sphere, rt.sphere_chain, t.sphere_mat);
+}
 
 enum : int { JOBS_EXPLICIT = 0, JOBS_PIXEL = 1, JOBS_CHUNK = 2 };
 
@@ -168,8 +184,9 @@ struct WfView {
 
 struct DeviceScene {
     int device = -1;
-    void *nodes = nullptr, *tris = nullptr, *tri_mat = nullptr, *spheres = nullptr, *sphere_mat = nullptr;
-    void *boxes = nullptr, *box_mat = nullptr, *cyls = nullptr, *cyl_mat = nullptr, *materials = nullptr;
+    void *nodes = nullptr, *tris = nullptr, *spheres = nullptr, *boxes = nullptr, *cyls = nullptr, *materials = nullptr;
+    void *prim_info = nullptr;
+    uint32_t info_box = 0, info_cyl = 0, info_sphere = 0;
     void *light_is_sphere = nullptr;
     void *tab = nullptr; /* image of the LDS tables (kTabF4 float4) */
     void *cold = nullptr; /* SceneCold */
@@ -178,7 +195,6 @@ struct DeviceScene {
     uint32_t light_count = 0;
     bool diffuse_only = false; /* no surface material can enter the specular / transmission blocks */
     void *ref_nodes = nullptr, *ref_recs = nullptr, *chain_boxes = nullptr;
-    void *tri_chain = nullptr, *sphere_chain = nullptr, *box_chain = nullptr, *cyl_chain = nullptr;
     void *tri_order = nullptr, *sphere_order = nullptr, *box_order = nullptr, *cyl_order = nullptr;
     void *bfs_pool = nullptr, *bfs_locks = nullptr;
     uint32_t bfs_queue_cap = 0, bfs_queue_count = 0;
@@ -212,6 +228,8 @@ enum : int { PS_NEED_JOB = 0, PS_PIXEL = 1, PS_SAMPLE = 2, PS_HIT = 3, PS_DONE =
 #define ORT_NEXT_JOB(p) ((*(p))++)
 #define ORT_COUNT(p, v) (*(p) += (v))
 #define ORT_TRY_LOCK(p) (*(p) == 0u ? (*(p) = 1u, true) : false)
+#define ORT_PEEK(p) (*(p))
+#define ORT_BACKOFF()
 #define ORT_UNLOCK(p) (*(p) = 0u)
 #define ORT_FENCE()
 #define ORT_FFS64(m) __builtin_ffsll((long long)(m))
@@ -232,6 +250,8 @@ enum : int { PS_NEED_JOB = 0, PS_PIXEL = 1, PS_SAMPLE = 2, PS_HIT = 3, PS_DONE =
 #define ORT_NEXT_JOB(p) atomicAdd((p), 1ull)
 #define ORT_COUNT(p, v) atomicAdd((p), (v))
 #define ORT_TRY_LOCK(p) (atomicCAS((p), 0u, 1u) == 0u)
+#define ORT_PEEK(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define ORT_BACKOFF() __builtin_amdgcn_s_sleep(64) /* 64 x 64 clocks, ~2 us */
 #define ORT_UNLOCK(p) ((void)atomicExch((p), 0u))
 #define ORT_FENCE() __threadfence()
 #define ORT_FFS64(m) __ffsll((unsigned long long)(m))
@@ -286,11 +306,9 @@ struct Prof { unsigned long long t = 0; bool on = false; };
 
 /* Branch-frequency hints on the exactness machinery of resolve_hit (chain walk of odd chains, phantom hits, re-traversals,
    the exact fallback): the register allocator weighs spill code by block frequency and this kernel lives at its
-   128-register cap, so telling it that these paths are rare moves the spills there: +4.4 % on the bunny room.  HINT is a
-   template parameter because the same hints cost the 1M-triangle scene 10 % (its launch is bound by what the L2 can take,
-   scratch traffic included: profiles/r02_tuning.md); hints on ties, deep stacks and the once-per-job blocks were neutral on
-   the one and harmful on the other and are not kept. */
-#define ORT_RARE(x) (HINT ? __builtin_expect(!!(x), 0) : !!(x))
+   128-register cap, so telling it that these paths are rare moves the spills there: +4.4 % on the bunny room.  (Hints on
+   ties, deep stacks and the once-per-job blocks were neutral or harmful and are not kept.) */
+#define ORT_RARE(x) __builtin_expect(!!(x), 0)
 constexpr uint32_t kNoPrim = 0xffffffffu;
 constexpr uint32_t kTraversalDone = 0xffffffffu; /* == EMPTY_CHILD: a leaf word no tree contains */
 
@@ -367,6 +385,45 @@ ORT_D void test_prim(const SceneView &sv, uint32_t kind, uint32_t slot, V3 org, 
    traversal tests everything in that window; an entry below t_other (and inside the window) is below
    any best the reference can have held.  Otherwise undecidable here: the caller re-casts exactly. */
 enum : int { CH_ADMIT = 0, CH_REJECT = 1, CH_UNKNOWN = 2 };
+
+ORT_D uint32_t info_index(const SceneView &sv, uint32_t prim) {
+    const uint32_t kind = prim >> 28, slot = prim & 0x00ffffffu;
+    return slot + ((kind == PRIM_TRI) ? 0u : (kind == PRIM_BOX) ? sv.info_box : (kind == PRIM_CYL) ? sv.info_cyl : sv.info_sphere);
+}
+
+/* A lane whose ray is finished knows its winner long before the wave gets to shade it (the other lanes are still
+   traversing): it asks for the winner's PrimInfo right away, with two loads that have no register destination
+   (LDS-DMA, global_load_lds_dword) and land in entries 0 and 1 of the lane's own, now idle, traversal stack.
+   resolve_hit picks them up after an s_waitcnt vmcnt(0): two dependent round trips (chain word, material index)
+   less on the critical path of every shading pass.  hipcc does not count these loads; its own waits only become
+   conservative by them (memory returns in order). */
+template <int BLOCK>
+ORT_D void announce_winner(const SceneView &sv, uint32_t prim, uint32_t *lds_stack, int tid) {
+    if (prim == kNoPrim) return;
+    const PrimInfo *p = sv.prim_info + info_index(sv, prim);
+#ifdef ORT_HOST_SIM
+    lds_stack[tid] = p->chain;
+    lds_stack[BLOCK + tid] = p->mat;
+#else
+    /* M0 = LDS byte address of the wave's 64 consecutive words of one stack entry; lane i lands at M0 + 4 i */
+    const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_stack + (tid & ~63)));
+    const uint32_t *q = &p->mat;
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\t"
+                 "s_add_u32 m0, %3, %4\n\ts_nop 0\n\tglobal_load_lds_dword %2, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(p), "v"(q), "s"(dst), "n"(BLOCK * 4) : "scc");
+#endif
+}
+
+/* the announced words of this lane (see announce_winner) */
+template <int BLOCK>
+ORT_D void announced_info(const uint32_t *lds_stack, int tid, uint32_t &chain, uint32_t &mat) {
+#ifndef ORT_HOST_SIM
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    chain = lds_stack[tid];
+    mat = lds_stack[BLOCK + tid];
+}
 /* CH_REJECT: never admitted whatever was found before (the ray misses the box or enters below 1e-6 from
    outside): the shapes below are invisible to this ray.  CH_UNKNOWN: enters at t_entry > t_hit with another
    hit possibly in between; t_entry is handed back in gap */
@@ -420,12 +477,11 @@ constexpr uint32_t kChainNested = 0x08000000u;
 #if defined(ORT_HOST_SIM) && defined(ORT_CHAIN_CROSSCHECK)
 static unsigned long long g_chain_crosschecks = 0;
 #endif
-template <bool HINT>
-ORT_D int chain_verdict(const SceneView &sv, uint32_t prim, V3 org, V3 inv_d, float t_hit, float t_other, float &gap) {
-    uint32_t kind = prim >> 28, slot = prim & 0x00ffffffu;
-    uint32_t word = (kind == PRIM_TRI) ? sv.tri_chain[slot]
-                  : (kind == PRIM_SPHERE) ? sv.sphere_chain[slot]
-                  : (kind == PRIM_BOX) ? sv.box_chain[slot] : sv.cyl_chain[slot];
+ORT_D int chain_verdict(const SceneView &sv, uint32_t word, V3 org, V3 inv_d, float t_hit, float t_other, float &gap) {
+#ifdef ORT_MEASURE_NO_CHAIN /* developer measurement only (wrong images): what the visibility-chain check costs, by leaving it out */
+    gap = 0.0f;
+    return CH_ADMIT;
+#endif
     const uint32_t len = word >> 28, first = word & 0x07ffffffu;
     gap = 0.0f;
     if (len == 0u) return CH_ADMIT;
@@ -436,24 +492,46 @@ ORT_D int chain_verdict(const SceneView &sv, uint32_t prim, V3 org, V3 inv_d, fl
     float4 jlo = dlo, jhi = dhi;
     bool found = false;
 #ifndef ORT_CHAIN_ROUND
-#define ORT_CHAIN_ROUND 2 /* boxes fetched per step from the top (2: 2210, 3: 2183, 4: 2166 Mpaths/s on the bunny room) */
+#define ORT_CHAIN_ROUND 2 /* boxes fetched per step of the (rare) scan below */
 #endif
-    /* the ancestors of the leaf box, from the top: entries len-1 .. 1 (none when the leaf hangs off the root's child) */
-    for (int32_t top = (int32_t)len - 1; !found && top >= 1; top -= ORT_CHAIN_ROUND) {
-        float4 lo[ORT_CHAIN_ROUND], hi[ORT_CHAIN_ROUND];
+    if (len >= 2u) {
+        /* ONE round of loads settles nearly every chain: the leaf box (above), its parent (entry 1), the top two
+           ancestors (entries len-1, len-2).  Origin inside the parent: inside every ancestor (nested), none to enter.
+           Otherwise the first box from the top that does not contain it is the top one, the next, or -- a long chain
+           with the origin inside its top two boxes -- found by scanning on down; the parent at the latest. */
+        const uint32_t it = len - 1u, it1 = (len >= 3u) ? len - 2u : 1u;
+        const float4 plo = sv.chain_boxes[2u * (first + 1u)], phi = sv.chain_boxes[2u * (first + 1u) + 1u];
+        const float4 tlo = sv.chain_boxes[2u * (first + it)], thi = sv.chain_boxes[2u * (first + it) + 1u];
+        const float4 ulo = sv.chain_boxes[2u * (first + it1)], uhi = sv.chain_boxes[2u * (first + it1) + 1u];
+        if (!in_rect_half_open(plo, phi, org)) {
+            found = true;
+            if (!in_rect_half_open(tlo, thi, org)) { jlo = tlo; jhi = thi; }
+            else if (!in_rect_half_open(ulo, uhi, org)) { jlo = ulo; jhi = uhi; }
+            else {
+                jlo = plo; jhi = phi;
+                bool hit = false;
+                for (int32_t top = (int32_t)len - 3; ORT_RARE(!hit && top >= 2); top -= ORT_CHAIN_ROUND) {
+                    float4 lo[ORT_CHAIN_ROUND], hi[ORT_CHAIN_ROUND];
 #pragma unroll
-        for (int32_t k = 0; k < ORT_CHAIN_ROUND; ++k) {
-            int32_t i = top - k;
-            i = (i > 1) ? i : 1; /* clamp: re-tests entry 1, harmless */
-            lo[k] = sv.chain_boxes[2u * (first + (uint32_t)i)];
-            hi[k] = sv.chain_boxes[2u * (first + (uint32_t)i) + 1u];
-        }
+                    for (int32_t k = 0; k < ORT_CHAIN_ROUND; ++k) {
+                        int32_t i = top - k;
+                        i = (i > 2) ? i : 2; /* clamp: re-tests entry 2, harmless */
+                        lo[k] = sv.chain_boxes[2u * (first + (uint32_t)i)];
+                        hi[k] = sv.chain_boxes[2u * (first + (uint32_t)i) + 1u];
+                    }
 #pragma unroll
-        for (int32_t k = 0; k < ORT_CHAIN_ROUND; ++k) {
-            const bool outside = !in_rect_half_open(lo[k], hi[k], org);
-            if (!found && outside) { jlo = lo[k]; jhi = hi[k]; found = true; }
+                    for (int32_t k = 0; k < ORT_CHAIN_ROUND; ++k) {
+                        const bool outside = !in_rect_half_open(lo[k], hi[k], org);
+                        if (!hit && outside) { jlo = lo[k]; jhi = hi[k]; hit = true; }
+                    }
+                }
+            }
         }
     }
+#if defined(ORT_HOST_SIM) && defined(ORT_CHAIN_STATS)
+    { extern unsigned long long g_cs[4][16]; int jj = -1; for (int32_t i = (int32_t)len - 1; i >= 1; --i) if (!in_rect_half_open(sv.chain_boxes[2u*(first+i)], sv.chain_boxes[2u*(first+i)+1u], org)) { jj = (int)len - 1 - i; break; }
+      g_cs[0][len]++; g_cs[1][jj < 0 ? 15 : jj]++; g_cs[2][(word >> 0) == 0 ? 0 : 1]++; }
+#endif
     /* found: an ancestor that does not contain the origin must be entered at t >= 1e-6.  Then, and when every
        ancestor contains the origin, the leaf box decides the rest (origin inside it, or the bounds on its entry
        distance): the entry distance only grows down the chain */
@@ -521,6 +599,7 @@ ORT_D bool ref_raycast_bfs(const SceneView &sv, V3 org, V3 dir, V3 inv_d, uint32
             }
         }
     }
+    ORT_COUNT(sv.cold->fallback_counters + kDiagFallback, (unsigned long long)tail); /* diagnostics (ORT_DEBUG_FALLBACK): nodes enqueued */
     return ok;
 }
 
@@ -552,6 +631,7 @@ struct HitState {
     uint32_t hit_prim = kNoPrim;
     float phantom_t = 0;
     float runner_t = 0; /* nearest hit other than the winner, exact below best_t * 1.0002 (kCullSlack) */
+    uint32_t hit_mat = 0; /* material index of hit_prim, 0 = no hit: set by resolve_hit */
 };
 
 /* position of pixel (x, y) in this shard's packed block layout [local block][pixel in block]: blocks are numbered
@@ -609,21 +689,29 @@ ORT_D void prologue_tests(const SceneView &sv, const float4 *tab, V3 org, V3 dir
    holding or waiting for a queue of the pool: a waiting lane can only wait for holders in other waves, which
    are running, never for a lane of its own wave parked at a reconvergence point.  The fences order the queue's
    contents across holders on different XCDs (each XCD has its own L2). */
-template <bool COUNTERS, bool HINT>
+template <bool COUNTERS>
 ORT_D void recast_exactly(const SceneView &sv, bool need, V3 org, V3 dir, V3 inv_d, uint32_t lane_id, HitState &h, Counters &c) {
     unsigned long long pending = ORT_BALLOT(need);
     while (ORT_RARE(pending != 0ull)) {
         const int leader = ORT_FFS64(pending) - 1;
         if (ORT_LANE() == leader) {
             ORT_COUNT(sv.cold->fallback_counters, 1ull); /* straight to memory, no register kept across the loop */
+            /* a queue of the pool: look before trying (a plain load does not serialise in L2 the way an atomic on a
+               contended line does) and back off between looks.  Without the back-off the lanes that wait slow the
+               breadth-first walks that hold the queues down (every load of theirs queues up behind the atomics), which
+               makes more lanes wait: on a long launch over a 1M-triangle scene that feedback halved the throughput */
             uint32_t slot = ((lane_id * 2654435761u) >> 8) % sv.cold->bfs_queue_count;
-            while (!ORT_TRY_LOCK(sv.cold->bfs_locks + slot)) slot = (slot + 1u) % sv.cold->bfs_queue_count;
+            while (ORT_PEEK(sv.cold->bfs_locks + slot * kBfsLockStride) != 0u || !ORT_TRY_LOCK(sv.cold->bfs_locks + slot * kBfsLockStride)) {
+                ORT_COUNT(sv.cold->fallback_counters + kDiagFallback + 2, 1ull); /* diagnostics (ORT_DEBUG_FALLBACK): busy queues met */
+                slot = (slot + 1u) % sv.cold->bfs_queue_count;
+                ORT_BACKOFF();
+            }
             ORT_FENCE();
             if (!ref_raycast_bfs<COUNTERS>(sv, org, dir, inv_d, sv.cold->bfs_pool + (size_t)slot * sv.cold->bfs_queue_cap, h.best_t, h.hit_n,
                                            h.hit_prim, c.nodes, c.tris, c.analytic))
                 ORT_COUNT(sv.cold->fallback_counters + 1, 1ull);
             ORT_FENCE();
-            ORT_UNLOCK(sv.cold->bfs_locks + slot);
+            ORT_UNLOCK(sv.cold->bfs_locks + slot * kBfsLockStride);
         }
         pending &= pending - 1ull;
     }
@@ -663,18 +751,7 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderHot &rv, const float4 *t
         if (P.ps == PS_HIT) {
             /* a traversal has finished: ray.cpp:817 then :1251-1277 (primary) or :1355-1421 (bounce) */
             bool alive = true;
-            uint32_t hit_mat = 0;
-            if (h.hit_prim != kNoPrim) {
-                uint32_t hk = h.hit_prim >> 28, hs = h.hit_prim & 0x00ffffffu;
-                if (TABS) {
-                    const uint32_t *tm = (const uint32_t *)tab;
-                    hit_mat = (hk == PRIM_TRI) ? sv.tri_mat[hs] : (hk == PRIM_SPHERE) ? tm[4 * kTabSphereMat + hs]
-                            : (hk == PRIM_BOX) ? tm[4 * kTabBoxMat + hs] : tm[4 * kTabCylMat + hs];
-                } else {
-                    hit_mat = (hk == PRIM_TRI) ? sv.tri_mat[hs] : (hk == PRIM_SPHERE) ? sv.sphere_mat[hs]
-                            : (hk == PRIM_BOX) ? sv.box_mat[hs] : sv.cyl_mat[hs];
-                }
-            }
+            const uint32_t hit_mat = h.hit_mat; /* resolve_hit: 0 = nothing hit */
             n = normalize(h.hit_n);
             ORT_SIM_RAY_HOOK((int)(P.pxy & 0xffffu), (int)(P.pxy >> 16), P.org, P.dir, h.best_t, n, hit_mat);
             if (COUNTERS && P.primary) c.paths++;
@@ -942,7 +1019,7 @@ ORT_D void begin_ray(const SceneView &sv, const float4 *tab, const PathState &P,
  * conservative; fminf/fmaxf drop the NaN of 0 * inf, i.e. that axis is ignored.
  * Returns when this lane's ray is finished, or -- refill_below > 0 -- as soon as fewer than
  * refill_below lanes of the wave are still traversing (the caller resumes later: all state is in T/h). */
-template <bool COUNTERS, int LDS_ENTRIES, int BLOCK, bool TREELET = false>
+template <bool COUNTERS, int LDS_ENTRIES, int BLOCK, bool TREELET = false, bool ANNOUNCE = false>
 ORT_D bool traverse(const SceneView &sv, V3 org, V3 dir, Trav &T, HitState &h, uint32_t *lds_stack, uint32_t *spill, int tid,
                     int refill_below, int descend_below, Counters &c, Prof &pr, uint32_t excl = kNoPrim, const float4 *tab = nullptr) {
     bool tracing = true;
@@ -1004,6 +1081,8 @@ ORT_D bool traverse(const SceneView &sv, V3 org, V3 dir, Trav &T, HitState &h, u
             }
             ORT_PHASE(pr, sv, 6, true);
         }
+        /* finished: the winner's chain word and material are wanted next (resolve_hit), ask for them now */
+        if (ANNOUNCE && !tracing) announce_winner<BLOCK>(sv, h.hit_prim, lds_stack, tid);
         /* when most of the wave has finished its ray, let the finished lanes shade and refill */
         if (refill_below > 0 && ORT_POPC64(ORT_BALLOT(tracing)) < refill_below) break;
     }
@@ -1027,17 +1106,29 @@ ORT_D bool traverse(const SceneView &sv, V3 org, V3 dir, Trav &T, HitState &h, u
    The extra traversals run here, to completion, for the lanes that need them (1e-5 of the rays of the
    reference's scenes, 1e-2 with slanted cylinders) while the rest of the wave waits: the shape to ignore is
    a local of this rare branch, not a register carried through every ray's traversal. */
-template <bool COUNTERS, bool TABS, int LDS_ENTRIES, int BLOCK, bool HINT = true>
+template <bool COUNTERS, bool TABS, int LDS_ENTRIES, int BLOCK, bool ANNOUNCED = false>
 ORT_D void resolve_hit(const SceneView &sv, const float4 *tab, V3 org, V3 dir, V3 inv_d, uint32_t lane_id, HitState &h, Counters &c, Prof &pr,
                        uint32_t *lds_stack, uint32_t *spill, int tid) {
+    /* the winner's chain word and material index: announced by the traversal (in the lane's stack entries 0 and 1),
+       or fetched here */
+    uint32_t word = 0, mat = 0;
+    if (ANNOUNCED) {
+        announced_info<BLOCK>(lds_stack, tid, word, mat);
+    } else if (h.hit_prim != kNoPrim) {
+        const PrimInfo pi = sv.prim_info[info_index(sv, h.hit_prim)];
+        word = pi.chain; mat = pi.mat;
+    }
+    bool stale = false; /* the winner has changed since */
     bool recast = sv.force_fallback_mask != 0xffffffffu && (om_f32_bits(dir.x) & sv.force_fallback_mask) == 0u;
     if (!ORT_RARE(recast)) {
         if (ORT_RARE(h.phantom_t <= h.best_t)) {
             recast = true;
         } else if (h.hit_prim != kNoPrim) {
             float gap = 0.0f;
-            const int verdict = chain_verdict<HINT>(sv, h.hit_prim, org, inv_d, h.best_t, fminf(h.runner_t, h.phantom_t), gap);
+            const int verdict = chain_verdict(sv, word, org, inv_d, h.best_t, fminf(h.runner_t, h.phantom_t), gap);
             if (ORT_RARE(verdict != CH_ADMIT)) {
+                stale = true;
+                ORT_COUNT(sv.cold->fallback_counters + kDiagFallback + 1, 1ull); /* diagnostics (ORT_DEBUG_FALLBACK): re-traversals */
                 /* W waits in the lane's (idle) traversal-stack slots of LDS, not in registers */
                 const uint32_t w_prim = h.hit_prim;
                 uint32_t *save = lds_stack + tid;
@@ -1064,12 +1155,14 @@ ORT_D void resolve_hit(const SceneView &sv, const float4 *tab, V3 org, V3 dir, V
                     recast = true;
                 } else if (h.hit_prim != kNoPrim) {
                     float gap2 = 0.0f;
-                    if (chain_verdict<HINT>(sv, h.hit_prim, org, inv_d, h.best_t, fminf(h.runner_t, h.phantom_t), gap2) != CH_ADMIT) recast = true;
+                    if (chain_verdict(sv, sv.prim_info[info_index(sv, h.hit_prim)].chain, org, inv_d, h.best_t, fminf(h.runner_t, h.phantom_t), gap2) != CH_ADMIT) recast = true;
                 }
             }
         }
     }
-    recast_exactly<COUNTERS, HINT>(sv, recast, org, dir, inv_d, lane_id, h, c);
+    recast_exactly<COUNTERS>(sv, recast, org, dir, inv_d, lane_id, h, c);
+    if (ORT_RARE(stale || recast)) mat = (h.hit_prim != kNoPrim) ? sv.prim_info[info_index(sv, h.hit_prim)].mat : 0u;
+    h.hit_mat = (h.hit_prim != kNoPrim) ? mat : 0u;
 }
 
 ORT_D void flush_counters(const RenderHot &rv, const Counters &c, bool all) {
@@ -1083,7 +1176,7 @@ ORT_D void flush_counters(const RenderHot &rv, const Counters &c, bool all) {
 }
 
 /* persistent mode: one lane runs jobs until the job space is empty */
-template <bool COUNTERS, bool DIFFUSE = false, bool TABS = false, bool IMPLICIT = false, bool HINT = true>
+template <bool COUNTERS, bool DIFFUSE = false, bool TABS = false, bool IMPLICIT = false>
 ORT_D void pt_lane(const SceneView &sv, const RenderHot &rv, const float4 *tab, uint32_t *lds_stack, float *lds_focal, const int tid,
                    const uint32_t lane_id, bool prof_on = false) {
     uint32_t spill[kSpillStack];
@@ -1103,7 +1196,7 @@ ORT_D void pt_lane(const SceneView &sv, const RenderHot &rv, const float4 *tab, 
             ORT_UTIL(sv, 3, true);
             ORT_UTIL(sv, 4, P.ps == PS_HIT);
             ORT_PHASE(pr, sv, 7, true);
-            if (P.ps == PS_HIT) resolve_hit<COUNTERS, TABS, kLdsStack, kBlock, HINT>(sv, tab, P.org, P.dir, T.inv_d, lane_id, h, c, pr, lds_stack, spill, tid);
+            if (P.ps == PS_HIT) resolve_hit<COUNTERS, TABS, kLdsStack, kBlock, true>(sv, tab, P.org, P.dir, T.inv_d, lane_id, h, c, pr, lds_stack, spill, tid);
             ORT_PHASE(pr, sv, 0, P.ps == PS_HIT);
             tracing = produce_ray<COUNTERS, DIFFUSE, TABS, IMPLICIT>(sv, rv, tab, P, h, c, pr, lds_focal + tid, kBlock, spp_u);
             if (tracing) {
@@ -1112,7 +1205,7 @@ ORT_D void pt_lane(const SceneView &sv, const RenderHot &rv, const float4 *tab, 
             }
         }
         if (ORT_BALLOT(P.ps != PS_DONE) == 0ull) break;
-        if (tracing) tracing = traverse<COUNTERS, kLdsStack, kBlock, TABS>(sv, P.org, P.dir, T, h, lds_stack, spill, tid, rv.refill_below, rv.descend_below, c, pr, kNoPrim, tab);
+        if (tracing) tracing = traverse<COUNTERS, kLdsStack, kBlock, TABS, true>(sv, P.org, P.dir, T, h, lds_stack, spill, tid, rv.refill_below, rv.descend_below, c, pr, kNoPrim, tab);
     }
     flush_counters(rv, c, COUNTERS);
 }
@@ -1140,7 +1233,8 @@ ORT_D uint32_t lane_rank(unsigned long long mask) { /* set bits of mask below th
 }
 
 constexpr uint32_t kStashVecs = 9u; /* float4 per parked path */
-ORT_D void stash_store(const Stash &st, uint32_t slot, const PathState &P, const HitState &h, uint32_t cur, int sp, V3 inv_d, const float *focal_cache) {
+ORT_D void stash_store(const Stash &st, uint32_t slot, const PathState &P, const HitState &h, uint32_t cur, int sp, V3 inv_d, const float *focal_cache,
+                       uint32_t info_chain = 0u, uint32_t info_mat = 0u) {
     float4 *r = st.rec + slot;
     const uint32_t cap = st.cap;
     r[0] = make_float4(P.org.x, P.org.y, P.org.z, P.dir.x);
@@ -1152,10 +1246,11 @@ ORT_D void stash_store(const Stash &st, uint32_t slot, const PathState &P, const
     r[6u * cap] = make_float4(P.wo.z, om_bits_f32(P.pxy), om_bits_f32(P.jyp), om_bits_f32(P.sample | (P.primary ? 0x80000000u : 0u)));
     /* 1/d and the pixel's focal point travel too: recomputing them costs more than two more stores and loads */
     r[7u * cap] = make_float4(inv_d.x, inv_d.y, inv_d.z, focal_cache[0]);
-    r[8u * cap] = make_float4(focal_cache[kBlock], focal_cache[2 * kBlock], 0.0f, 0.0f);
+    /* a finished ray's announced winner info (R stash; announce_winner) */
+    r[8u * cap] = make_float4(focal_cache[kBlock], focal_cache[2 * kBlock], om_bits_f32(info_chain), om_bits_f32(info_mat));
 }
 
-ORT_D void stash_load(const Stash &st, uint32_t slot, const RenderHot &rv, PathState &P, HitState &h, Trav &T, float *focal_cache) {
+ORT_D void stash_load(const Stash &st, uint32_t slot, const RenderHot &rv, PathState &P, HitState &h, Trav &T, float *focal_cache, uint32_t *lds_info) {
     const float4 *r = st.rec + slot;
     const uint32_t cap = st.cap;
     const float4 a = r[0], b = r[cap], c = r[2u * cap], d = r[3u * cap], e = r[4u * cap], f = r[5u * cap], g = r[6u * cap];
@@ -1171,6 +1266,8 @@ ORT_D void stash_load(const Stash &st, uint32_t slot, const RenderHot &rv, PathS
     P.ps = PS_HIT;
     T.inv_d = mk(i.x, i.y, i.z);
     focal_cache[0] = i.w; focal_cache[kBlock] = j.x; focal_cache[2 * kBlock] = j.y;
+    /* where resolve_hit looks for them (an L path refills its stack over them: it has not finished yet) */
+    lds_info[0] = om_f32_bits(j.z); lds_info[kBlock] = om_f32_bits(j.w);
 }
 
 template <bool COUNTERS, bool DIFFUSE, bool TABS>
@@ -1214,10 +1311,10 @@ ORT_D void pt_lane_x(const SceneView &sv, const RenderHot &rv, const float4 *tab
             const uint32_t rrank = lane_rank(m_recv);
             const bool take_r = is_free && rrank < rtop;
             const bool take_l = is_free && !take_r && rrank - rtop < ltop;
-            if (take_r) stash_load(R, rtop - 1u - rrank, rv, P, h, T, focal_cache);
+            if (take_r) stash_load(R, rtop - 1u - rrank, rv, P, h, T, focal_cache, lds_stack + tid);
             if (take_l) {
                 const uint32_t slot = ltop - 1u - (rrank - rtop);
-                stash_load(L, slot, rv, P, h, T, focal_cache);
+                stash_load(L, slot, rv, P, h, T, focal_cache, lds_stack + tid);
                 for (int lv = 0; lv < T.sp; ++lv) lds_stack[lv * kBlock + tid] = L.stk[(uint32_t)lv * L.cap + slot];
                 tracing = true;
             }
@@ -1235,7 +1332,12 @@ ORT_D void pt_lane_x(const SceneView &sv, const RenderHot &rv, const float4 *tab
             const bool is_done = !tracing && P.ps == PS_HIT;
             const uint32_t drank = lane_rank(m_done);
             const bool park = is_done && drank < need_done;
-            if (park) { stash_store(R, rtop + drank, P, h, 0u, 0, T.inv_d, focal_cache); P.ps = PS_NEED_JOB; }
+            if (park) {
+                uint32_t info_chain, info_mat;
+                announced_info<kBlock>(lds_stack, tid, info_chain, info_mat);
+                stash_store(R, rtop + drank, P, h, 0u, 0, T.inv_d, focal_cache, info_chain, info_mat);
+                P.ps = PS_NEED_JOB;
+            }
             rtop += need_done < (uint32_t)__popcll(m_done) ? need_done : (uint32_t)__popcll(m_done);
             const bool is_free = !tracing && P.ps != PS_HIT; /* includes the lanes that parked just now */
             const unsigned long long m_recv = __ballot(is_free);
@@ -1243,7 +1345,7 @@ ORT_D void pt_lane_x(const SceneView &sv, const RenderHot &rv, const float4 *tab
             const bool take = is_free && rrank < ltop;
             if (take) {
                 const uint32_t slot = ltop - 1u - rrank;
-                stash_load(L, slot, rv, P, h, T, focal_cache);
+                stash_load(L, slot, rv, P, h, T, focal_cache, lds_stack + tid);
                 for (int lv = 0; lv < T.sp; ++lv) lds_stack[lv * kBlock + tid] = L.stk[(uint32_t)lv * L.cap + slot];
                 tracing = true;
             }
@@ -1274,7 +1376,7 @@ ORT_D void pt_lane_x(const SceneView &sv, const RenderHot &rv, const float4 *tab
             const uint32_t rrank = lane_rank(m_recv);
             const bool take = is_free && rrank < rtop;
             if (take) {
-                stash_load(R, rtop - 1u - rrank, rv, P, h, T, focal_cache);
+                stash_load(R, rtop - 1u - rrank, rv, P, h, T, focal_cache, lds_stack + tid);
             }
             const uint32_t n_recv = (uint32_t)__popcll(m_recv);
             rtop -= n_recv < rtop ? n_recv : rtop;
@@ -1285,7 +1387,7 @@ ORT_D void pt_lane_x(const SceneView &sv, const RenderHot &rv, const float4 *tab
             ORT_UTIL(sv, 3, true);
             ORT_UTIL(sv, 4, P.ps == PS_HIT);
             ORT_PHASE(pr, sv, 7, true);
-            if (P.ps == PS_HIT) resolve_hit<COUNTERS, TABS, kLdsStack, kBlock>(sv, tab, P.org, P.dir, T.inv_d, lane_id, h, c, pr, lds_stack, spill, tid);
+            if (P.ps == PS_HIT) resolve_hit<COUNTERS, TABS, kLdsStack, kBlock, true>(sv, tab, P.org, P.dir, T.inv_d, lane_id, h, c, pr, lds_stack, spill, tid);
             ORT_PHASE(pr, sv, 0, P.ps == PS_HIT);
             tracing = produce_ray<COUNTERS, DIFFUSE, TABS, true>(sv, rv, tab, P, h, c, pr, focal_cache, kBlock, spp_u);
             if (tracing) {
@@ -1297,7 +1399,7 @@ ORT_D void pt_lane_x(const SceneView &sv, const RenderHot &rv, const float4 *tab
         /* in a traversal phase come back for more parked rays when half the lanes have finished; otherwise (and once
            L is empty) when only stragglers are left, which then park */
         const int below = (long_phase && ltop > 0u) ? (int)rv.c->long_refill : rv.refill_below;
-        if (tracing) tracing = traverse<COUNTERS, kLdsStack, kBlock, TABS>(sv, P.org, P.dir, T, h, lds_stack, spill, tid, below, rv.descend_below, c, pr, kNoPrim, tab);
+        if (tracing) tracing = traverse<COUNTERS, kLdsStack, kBlock, TABS, true>(sv, P.org, P.dir, T, h, lds_stack, spill, tid, below, rv.descend_below, c, pr, kNoPrim, tab);
     }
     flush_counters(rv, c, COUNTERS);
 }
@@ -1329,6 +1431,7 @@ ORT_D bool wf_shade_slot(const SceneView &sv, const RenderHot &rv, const float4 
         P.job_index = q3.x; P.pxy = q3.y; P.jxx = q3.z; P.jyp = q3.w;
         P.primary = (fl & WF_PRIMARY) != 0;
         h.best_t = hh.x; h.hit_n = mk(hh.y, hh.z, hh.w); h.hit_prim = wf.hitp[i];
+        h.hit_mat = (P.ps == PS_HIT && h.hit_prim != kNoPrim) ? sv.prim_info[info_index(sv, h.hit_prim)].mat : 0u;
     }
     Prof pr;
     bool tracing = produce_ray<COUNTERS>(sv, rv, tab, P, h, c, pr);
@@ -1395,7 +1498,7 @@ __device__ __forceinline__ void fill_tab(const SceneView &sv, float4 *lds_tab) {
     __syncthreads();
 }
 
-template <bool COUNTERS, bool DIFFUSE, bool TABS, bool IMPLICIT = false, bool HINT = true>
+template <bool COUNTERS, bool DIFFUSE, bool TABS, bool IMPLICIT = false>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(ORT_WAVES_PER_EU, ORT_WAVES_PER_EU)))
 pt_persistent(SceneView sv, RenderHot rv) {
     __shared__ uint32_t lds_stack[kLdsStack * kBlock];
@@ -1408,7 +1511,7 @@ pt_persistent(SceneView sv, RenderHot rv) {
         if (threadIdx.x < 4) g_lds_prof[96 + threadIdx.x] = __builtin_amdgcn_s_memtime();
         __syncthreads();
     }
-    pt_lane<COUNTERS, DIFFUSE, TABS, IMPLICIT, HINT>(sv, rv, lds_tab, lds_stack, lds_focal, (int)threadIdx.x, blockIdx.x * (uint32_t)kBlock + threadIdx.x, prof);
+    pt_lane<COUNTERS, DIFFUSE, TABS, IMPLICIT>(sv, rv, lds_tab, lds_stack, lds_focal, (int)threadIdx.x, blockIdx.x * (uint32_t)kBlock + threadIdx.x, prof);
     if (prof) {
         __syncthreads();
         if (threadIdx.x < 96 && g_lds_prof[threadIdx.x]) atomicAdd(sv.util + threadIdx.x, g_lds_prof[threadIdx.x]);
@@ -1575,9 +1678,8 @@ void device_release(Scene *scene) {
     DeviceScene *d = scene->dev;
     if (!d) return;
     (void)hipSetDevice(d->device);
-    void *ptrs[] = {d->nodes, d->tris, d->tri_mat, d->spheres, d->sphere_mat, d->boxes, d->box_mat, d->cyls, d->cyl_mat,
-                    d->materials, d->light_is_sphere, d->tab, d->cold, d->rv_dev, d->ref_nodes, d->ref_recs, d->chain_boxes, d->tri_chain, d->sphere_chain,
-                    d->box_chain, d->cyl_chain, d->tri_order, d->sphere_order, d->box_order, d->cyl_order, d->bfs_pool, d->bfs_locks, d->ctrl, d->partial, d->staging, d->jobs, d->states};
+    void *ptrs[] = {d->nodes, d->tris, d->spheres, d->boxes, d->cyls, d->prim_info,
+                    d->materials, d->light_is_sphere, d->tab, d->cold, d->rv_dev, d->ref_nodes, d->ref_recs, d->chain_boxes, d->tri_order, d->sphere_order, d->box_order, d->cyl_order, d->bfs_pool, d->bfs_locks, d->ctrl, d->partial, d->staging, d->jobs, d->states};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (d->wf_mem) (void)hipFree(d->wf_mem);
@@ -1604,13 +1706,14 @@ int device_upload(Scene *scene, int device, std::string *err) {
     const Tree &t = scene->tree;
     if ((rc = upload_vec(t.nodes, &d->nodes, err))) return rc;
     if ((rc = upload_vec(t.tris, &d->tris, err))) return rc;
-    if ((rc = upload_vec(t.tri_mat, &d->tri_mat, err))) return rc;
     if ((rc = upload_vec(t.spheres, &d->spheres, err))) return rc;
-    if ((rc = upload_vec(t.sphere_mat, &d->sphere_mat, err))) return rc;
     if ((rc = upload_vec(t.boxes, &d->boxes, err))) return rc;
-    if ((rc = upload_vec(t.box_mat, &d->box_mat, err))) return rc;
     if ((rc = upload_vec(t.cyls, &d->cyls, err))) return rc;
-    if ((rc = upload_vec(t.cyl_mat, &d->cyl_mat, err))) return rc;
+    {
+        std::vector<PrimInfo> info;
+        build_prim_info(t, scene->ref, info, d->info_box, d->info_cyl, d->info_sphere);
+        if ((rc = upload_vec(info, &d->prim_info, err))) return rc;
+    }
     std::vector<DevMaterial> mats(scene->materials.size());
     for (size_t i = 0; i < mats.size(); ++i) mats[i] = make_dev_material(scene->materials[i]);
     if ((rc = upload_vec(mats, &d->materials, err))) return rc;
@@ -1627,7 +1730,7 @@ int device_upload(Scene *scene, int device, std::string *err) {
     d->light_count = (uint32_t)lis.size();
     if ((rc = upload_vec(lis, &d->light_is_sphere, err))) return rc;
     {
-        /* the image of the LDS tables: root node, prologue shapes, light flags, material indices, materials */
+        /* the image of the LDS tables: root node, prologue shapes, light flags, materials */
         std::vector<float4> tab((size_t)kTabF4, make_float4(0, 0, 0, 0));
         uint32_t *tw = (uint32_t *)tab.data();
         d->tab_flags = 0;
@@ -1650,12 +1753,6 @@ int device_upload(Scene *scene, int device, std::string *err) {
             if (!lis.empty()) memcpy(tw + 4 * kTabLights, lis.data(), lis.size() * 4u);
             d->tab_flags |= TAB_LIGHTS;
         }
-        if (t.box_mat.size() <= (size_t)kTabPrimMatCap && t.sphere_mat.size() <= (size_t)kTabPrimMatCap && t.cyl_mat.size() <= (size_t)kTabPrimMatCap) {
-            if (!t.box_mat.empty()) memcpy(tw + 4 * kTabBoxMat, t.box_mat.data(), t.box_mat.size() * 4u);
-            if (!t.sphere_mat.empty()) memcpy(tw + 4 * kTabSphereMat, t.sphere_mat.data(), t.sphere_mat.size() * 4u);
-            if (!t.cyl_mat.empty()) memcpy(tw + 4 * kTabCylMat, t.cyl_mat.data(), t.cyl_mat.size() * 4u);
-            d->tab_flags |= TAB_PRIM_MATS;
-        }
         if (mats.size() <= (size_t)kTabMatCap) {
             memcpy(&tab[kTabMats], mats.data(), mats.size() * sizeof(DevMaterial));
             d->tab_flags |= TAB_MATS;
@@ -1666,10 +1763,6 @@ int device_upload(Scene *scene, int device, std::string *err) {
     if ((rc = upload_vec(rt.nodes, &d->ref_nodes, err))) return rc;
     if ((rc = upload_vec(rt.recs, &d->ref_recs, err))) return rc;
     if ((rc = upload_vec(rt.chain_boxes, &d->chain_boxes, err))) return rc;
-    if ((rc = upload_vec(rt.tri_chain, &d->tri_chain, err))) return rc;
-    if ((rc = upload_vec(rt.sphere_chain, &d->sphere_chain, err))) return rc;
-    if ((rc = upload_vec(rt.box_chain, &d->box_chain, err))) return rc;
-    if ((rc = upload_vec(rt.cyl_chain, &d->cyl_chain, err))) return rc;
     if ((rc = upload_vec(rt.tri_order, &d->tri_order, err))) return rc;
     if ((rc = upload_vec(rt.sphere_order, &d->sphere_order, err))) return rc;
     if ((rc = upload_vec(rt.box_order, &d->box_order, err))) return rc;
@@ -1694,8 +1787,8 @@ int device_upload(Scene *scene, int device, std::string *err) {
     size_t fit = kBfsPoolBytes / ((size_t)d->bfs_queue_cap * sizeof(uint32_t));
     d->bfs_queue_count = (uint32_t)(fit < 16 ? 16 : (fit > kBfsPoolQueues ? kBfsPoolQueues : fit));
     ORT_HIP(hipMalloc(&d->bfs_pool, (size_t)d->bfs_queue_count * d->bfs_queue_cap * sizeof(uint32_t)));
-    ORT_HIP(hipMalloc(&d->bfs_locks, (size_t)d->bfs_queue_count * sizeof(uint32_t)));
-    ORT_HIP(hipMemset(d->bfs_locks, 0, (size_t)d->bfs_queue_count * sizeof(uint32_t)));
+    ORT_HIP(hipMalloc(&d->bfs_locks, (size_t)d->bfs_queue_count * kBfsLockStride * sizeof(uint32_t)));
+    ORT_HIP(hipMemset(d->bfs_locks, 0, (size_t)d->bfs_queue_count * kBfsLockStride * sizeof(uint32_t)));
     ORT_HIP(hipHostMalloc((void **)&d->h_active, sizeof(unsigned long long)));
     {
         SceneCold cold{};
@@ -1840,10 +1933,10 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
     }
 
     SceneView sv{};
-    sv.nodes = (const float4 *)d->nodes; sv.tris = (const float4 *)d->tris; sv.tri_mat = (const uint32_t *)d->tri_mat;
-    sv.spheres = (const float4 *)d->spheres; sv.sphere_mat = (const uint32_t *)d->sphere_mat;
-    sv.boxes = (const float4 *)d->boxes; sv.box_mat = (const uint32_t *)d->box_mat;
-    sv.cyls = (const float4 *)d->cyls; sv.cyl_mat = (const uint32_t *)d->cyl_mat;
+    sv.nodes = (const float4 *)d->nodes; sv.tris = (const float4 *)d->tris;
+    sv.spheres = (const float4 *)d->spheres; sv.boxes = (const float4 *)d->boxes; sv.cyls = (const float4 *)d->cyls;
+    sv.prim_info = (const PrimInfo *)d->prim_info;
+    sv.info_box = d->info_box; sv.info_cyl = d->info_cyl; sv.info_sphere = d->info_sphere;
     sv.materials = (const float4 *)d->materials;
     sv.light_is_sphere = (const uint32_t *)d->light_is_sphere;
     sv.tab_src = (const float4 *)d->tab;
@@ -1853,8 +1946,6 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
     sv.pro_spheres = scene->tree.pro_spheres;
     sv.pro_cyls = scene->tree.pro_cyls;
     sv.chain_boxes = (const float4 *)d->chain_boxes;
-    sv.tri_chain = (const uint32_t *)d->tri_chain; sv.sphere_chain = (const uint32_t *)d->sphere_chain;
-    sv.box_chain = (const uint32_t *)d->box_chain; sv.cyl_chain = (const uint32_t *)d->cyl_chain;
     const char *ff = getenv("ORT_DEBUG_FORCE_FALLBACK");
     sv.force_fallback_mask = ff ? (uint32_t)strtoul(ff, nullptr, 0) : 0xffffffffu;
     sv.cold = (const ORT_CONSTANT_AS SceneCold *)d->cold;
@@ -1874,7 +1965,8 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
         /* tuning knobs; results do not depend on them.  Defaults tuned on MI355X (profiles/r01_tuning.md)
            separately for trees that stay in L2 and trees that do not */
         const size_t fast_tree_bytes = scene->tree.nodes.size() * sizeof(DevNode) + scene->tree.tris.size() * sizeof(DevTri);
-        const bool cache_resident = fast_tree_bytes <= (size_t)(16u << 20);
+        const char *cr = getenv("ORT_CACHE_RESIDENT"); /* A/B runs: treat the tree as (not) cache-resident */
+        const bool cache_resident = cr ? atoi(cr) != 0 : fast_tree_bytes <= (size_t)(16u << 20);
         cache_resident_tree = cache_resident;
         const char *e = getenv("ORT_REFILL_BELOW");
         rv.refill_below = e ? atoi(e) : (cache_resident ? 12 : 32);
@@ -1882,11 +1974,8 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
         if (rv.refill_below > 64) rv.refill_below = 64;
         e = getenv("ORT_DESCEND_BELOW");
         /* cache-resident trees (bunny room: 6 MB): 8, worth +10 %.  Trees that leave the 8 x 4 MB of L2 (the 1M-triangle
-           scene, 86 MB): 16 -- 942 Mpaths/s against 667 with the plain while-while loop (3840x2160, 256 spp;
-           profiles/r02_tuning.md).  Round 1 had to switch the early exit off there; what collapsed was the COMBINATION
-           with the analytic prologue, which turns the register spills around the loop into a write storm that the L2
-           cannot absorb next to an 86 MB tree (255 GB written instead of 2.5, TCC_TAG_STALL x 50 000); the prologue
-           stays off for such trees (ort_tree.cpp) and each of the two alone is a gain */
+           scene, 86 MB): 16 and a later refill (32): the waits are longer there, so leaving the loops costs more
+           (3840x2160, 256 spp: 1 272 Mpaths/s; with the small-tree values 1 100; profiles/r02_tuning.md) */
         rv.descend_below = e ? atoi(e) : (cache_resident ? 8 : 16);
         if (rv.descend_below < 0) rv.descend_below = 0;
         if (rv.descend_below > 64) rv.descend_below = 64;
@@ -1939,7 +2028,7 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
     const char *kenv = getenv("ORT_KERNEL"); /* "general" forces the all-lobes kernel (A/B runs; same results) */
     const bool diffuse = d->diffuse_only && !(kenv && strcmp(kenv, "general") == 0);
     /* TABS: the scene's small tables all fit their LDS slots (every scene of this repository); otherwise HBM */
-    const uint32_t all_tabs = TAB_PRO | TAB_LIGHTS | TAB_PRIM_MATS | TAB_MATS;
+    const uint32_t all_tabs = TAB_PRO | TAB_LIGHTS | TAB_MATS;
     const char *tenv = getenv("ORT_LDS_TABLES"); /* "0": read them from HBM anyway (A/B runs; same results) */
     const bool tabs = (d->tab_flags & all_tabs) == all_tabs && !(tenv && atoi(tenv) == 0);
     bool exch = false;
@@ -1950,8 +2039,7 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
            launches of at least 24 jobs per lane -- every parked path is a job in progress, so a wave's tail grows with
            what it has parked, which short launches and 8-way shards cannot amortise.  ORT_EXCHANGE=0 / 1 forces it. */
         const char *xenv = getenv("ORT_EXCHANGE");
-        /* ... and not for trees that leave the L2 (the 1M-triangle scene: 875 vs 930 Mpaths/s): there the stash traffic
-           competes with the tree for the cache */
+        /* ... and not for trees that leave the L2 (the 1M-triangle scene: 1 268 with it, 1 272 without) */
         const bool worth_it = diffuse && cache_resident_tree && rv.job_count >= 24ull * (unsigned long long)grid * kBlock;
         exch = tabs && rv.mode != JOBS_EXPLICIT && (xenv ? atoi(xenv) != 0 : worth_it) && (!counters || (want_util && diffuse));
         if (exch && !getenv("ORT_REFILL_BELOW")) rv.refill_below = 16; /* stragglers park instead of idling: leave the loop a little earlier */
@@ -1992,10 +2080,6 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
         if (counters && diffuse && want_util) { if (tabs) ORT_LAUNCH(true, true, true); else ORT_LAUNCH(true, true, false); }
         else if (counters) { if (tabs) ORT_LAUNCH(true, false, true); else ORT_LAUNCH(true, false, false); }
         /* IMPLICIT job spaces (PIXEL / CHUNK policies): the variant whose lanes carry no job rect / count / index */
-        else if (tabs && rv.mode != JOBS_EXPLICIT && !cache_resident_tree) { /* trees that leave the L2: the variant without frequency hints (ORT_RARE) */
-            if (diffuse) hipLaunchKernelGGL((pt_persistent<false, true, true, true, false>), dim3(grid), dim3(kBlock), 0, stream, sv, hot);
-            else hipLaunchKernelGGL((pt_persistent<false, false, true, true, false>), dim3(grid), dim3(kBlock), 0, stream, sv, hot);
-        }
         else if (diffuse) { if (tabs && rv.mode != JOBS_EXPLICIT) hipLaunchKernelGGL((pt_persistent<false, true, true, true>), dim3(grid), dim3(kBlock), 0, stream, sv, hot);
                             else if (tabs) ORT_LAUNCH(false, true, true); else ORT_LAUNCH(false, true, false); }
         else { if (tabs && rv.mode != JOBS_EXPLICIT) hipLaunchKernelGGL((pt_persistent<false, false, true, true>), dim3(grid), dim3(kBlock), 0, stream, sv, hot);
@@ -2024,16 +2108,25 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
         ORT_HIP(hipMemcpy(&ovf, d->ctrl + 7, sizeof(ovf), hipMemcpyDeviceToHost));
         if (ovf) { *err = "reference-order fallback queue overflowed"; return ORT_ERR_UNSUPPORTED; }
     }
+    if (stats && getenv("ORT_DEBUG_FALLBACK")) { /* developer diagnostics */
+        unsigned long long fb[2], dg[3];
+        ORT_HIP(hipMemcpy(fb, d->ctrl + 6, sizeof(fb), hipMemcpyDeviceToHost));
+        ORT_HIP(hipMemcpy(dg, d->ctrl + 6 + kDiagFallback, sizeof(dg), hipMemcpyDeviceToHost));
+        fprintf(stderr, "fallback: %llu rays traversed again without their first winner, %llu re-cast exactly (%llu octree nodes enqueued, %llu busy queues met)\n",
+                dg[1], fb[0], dg[0], dg[2]);
+    }
     if (stats) {
         memset(stats, 0, sizeof(*stats));
         float ms = 0;
         ORT_HIP(hipEventElapsedTime(&ms, d->ev0, d->ev1));
         stats->kernel_ms = ms;
-        if (counters) {
+        {
             unsigned long long c[6];
             ORT_HIP(hipMemcpy(c, d->ctrl + 1, sizeof(c), hipMemcpyDeviceToHost));
-            stats->paths = c[0]; stats->rays = c[1]; stats->node_tests = c[2]; stats->tri_tests = c[3]; stats->analytic_tests = c[4];
-            stats->fallback_rays = c[5];
+            stats->fallback_rays = c[5]; /* counted by every kernel flavour (straight to memory, rare) */
+            if (counters) { stats->paths = c[0]; stats->rays = c[1]; stats->node_tests = c[2]; stats->tri_tests = c[3]; stats->analytic_tests = c[4]; }
+        }
+        if (counters) {
             if (want_util) {
                 static const char *names[8] = {"node visit", "leaf visit", "traverse outer iteration", "shade call", "  of which lanes with a finished ray",
                                                "produce_ray pass", "  bounce draw", "  sin/cos + ray setup"};

@@ -473,11 +473,9 @@ int build_tree(Scene *scene, std::string *err) {
            wave on the same shape at the same time, than to reach through tree nodes in divergent lanes:
            they stay out of the tree and form the ray's prologue (tuned on MI355X, profiles/r01_tuning.md) */
         const char *pro_env = getenv("ORT_ANALYTIC_PROLOGUE");
-        /* not for trees that leave the L2 (C5, 86 MB): there the launch is bound by the memory system, which
-           collapses when the kernel gets more efficient at full occupancy -- 527 Mpaths/s without the prologue,
-           255 with it at 4 workgroups per CU, 522 with it at 3 (profiles/r01_tuning.md) */
-        const bool cache_resident = (b.prims.size() - n_analytic) * (sizeof(DevTri) + 32u) <= (size_t)(16u << 20);
-        const float pro_budget = pro_env ? (float)atof(pro_env) : (cache_resident ? kPrologueBudget : 0.0f);
+        /* (trees of every size: the collapse rounds 1 and 2 saw with it on the 1M-triangle scene was the lock pool of
+           the exact fallback, ort_kernels.hip recast_exactly -- with that cured the prologue is worth +23 % there) */
+        const float pro_budget = pro_env ? (float)atof(pro_env) : kPrologueBudget;
         /* cheapest kinds first (a sphere test costs about 1.5 box tests, a cylinder about 5), as many as fit */
         auto cost_of = [](const Prim &p) { return p.kind == PRIM_BOX ? 1.0f : p.kind == PRIM_SPHERE ? 1.5f : 5.0f; };
         /* within a kind the largest shapes first: they are the ones most rays hit */

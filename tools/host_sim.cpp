@@ -23,6 +23,10 @@ static int g_dbg_x = -1, g_dbg_y = -1; static FILE *g_ray_log;
 #include <chrono>
 
 using namespace ort;
+#ifdef ORT_CHAIN_STATS
+namespace ort { unsigned long long g_cs[4][16]; }
+static void cs_dump() { for (int k = 0; k < 2; ++k) { fprintf(stderr, k ? "first-outside depth from top (15 = none):" : "chain len:"); for (int i = 0; i < 16; ++i) fprintf(stderr, " %llu", g_cs[k][i]); fprintf(stderr, "\n"); } }
+#endif
 
 int main(int argc, char **argv) {
     if (argc < 10) { fprintf(stderr, "usage: host_sim scn base W H spp seed policy chunk out.f32 [shard_index shard_count]\n"); return 2; }
@@ -46,17 +50,17 @@ int main(int argc, char **argv) {
     for (size_t i = 0; i < lis.size(); ++i) lis[i] = scene->lights[i].type == 1u;
 
     SceneView sv{};
-    sv.nodes = (const float4 *)t.nodes.data(); sv.tris = (const float4 *)t.tris.data(); sv.tri_mat = t.tri_mat.data();
-    sv.spheres = (const float4 *)t.spheres.data(); sv.sphere_mat = t.sphere_mat.data();
-    sv.boxes = (const float4 *)t.boxes.data(); sv.box_mat = t.box_mat.data();
-    sv.cyls = (const float4 *)t.cyls.data(); sv.cyl_mat = t.cyl_mat.data();
+    sv.nodes = (const float4 *)t.nodes.data(); sv.tris = (const float4 *)t.tris.data();
+    sv.spheres = (const float4 *)t.spheres.data(); sv.boxes = (const float4 *)t.boxes.data(); sv.cyls = (const float4 *)t.cyls.data();
+    static std::vector<PrimInfo> prim_info;
+    build_prim_info(t, scene->ref, prim_info, sv.info_box, sv.info_cyl, sv.info_sphere);
+    sv.prim_info = prim_info.data();
     sv.materials = (const float4 *)mats.data();
     sv.light_is_sphere = lis.data(); sv.light_count = (uint32_t)lis.size();
     sv.pro_boxes = t.pro_boxes; sv.pro_spheres = t.pro_spheres; sv.pro_cyls = t.pro_cyls;
     const RefTree &rt = scene->ref;
     static SceneCold cold; sv.cold = &cold;
     cold.ref_nodes = (const float4 *)rt.nodes.data(); cold.ref_recs = rt.recs.data(); sv.chain_boxes = (const float4 *)rt.chain_boxes.data();
-    sv.tri_chain = rt.tri_chain.data(); sv.sphere_chain = rt.sphere_chain.data(); sv.box_chain = rt.box_chain.data(); sv.cyl_chain = rt.cyl_chain.data();
     cold.tri_order = rt.tri_order.data(); cold.sphere_order = rt.sphere_order.data(); cold.box_order = rt.box_order.data(); cold.cyl_order = rt.cyl_order.data();
     fprintf(stderr, "ref octree: %zu nodes, %u leaves, max leaf %u, chain boxes %zu\n", rt.nodes.size(), rt.nonempty_leaves, rt.max_leaf_records, rt.chain_boxes.size() / 2);
     ort_camera cam;
@@ -137,6 +141,10 @@ int main(int argc, char **argv) {
     if (rv.mode == JOBS_CHUNK)
         for (unsigned long long i = 0; i < (unsigned long long)rv.my_blocks * 64; ++i) combine_pixel(hot, i);
     double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    
+#ifdef ORT_CHAIN_STATS
+    cs_dump();
+#endif
     fprintf(stderr, "sim: %.2fs paths %llu rays %llu node_tests %llu tri_tests %llu analytic %llu fallback %llu overflow %llu%s\n", sec, ctrl[1], ctrl[2], ctrl[3], ctrl[4], ctrl[5], ctrl[6], ctrl[7],
             finals.empty() ? "" : (" final_rng " + std::to_string(finals.back())).c_str());
 #ifdef ORT_CHAIN_CROSSCHECK

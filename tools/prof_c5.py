@@ -19,7 +19,7 @@ scene.upload(0); t4 = time.time()
 print("generate %.2fs parse %.2fs commit %.2fs upload %.2fs; %d triangles; tree %s" % (t1 - t0, t2 - t1, t3 - t2, t4 - t3, nf, scene.tree_info()), flush=True)
 for i in range(reps):
     img, st = scene.render(W, H, spp, 12345, "chunk", chunk=chunk)
-    print("rep", i, "kernel_ms %.2f -> %.1f Mpaths/s" % (st["kernel_ms"], W * H * spp / st["kernel_ms"] / 1e3), flush=True)
+    print("rep", i, "fallback_rays", st.get("fallback_rays"), "kernel_ms %.2f -> %.1f Mpaths/s" % (st["kernel_ms"], W * H * spp / st["kernel_ms"] / 1e3), flush=True)
 img, st = scene.render(W, H, min(spp, 8), 12345, "chunk", chunk=min(chunk, 8), counters=True)
 R = st["rays"] / st["paths"]; Vn = st["node_tests"] / st["rays"]; Vt = st["tri_tests"] / st["rays"]; Vp = st["analytic_tests"] / st["rays"]
 print("rays/path %.2f node/ray %.1f tri/ray %.2f analytic/ray %.2f -> %.0f B/path; fallback rays %d" % (R, Vn, Vt, Vp, R * (Vn * 32 + Vt * 36 + Vp * 32), st["fallback_rays"]))
