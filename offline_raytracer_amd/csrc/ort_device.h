@@ -219,6 +219,76 @@ ORT_D float pdf_brdf(V3 N, V3 wi, V3 wo, float rough, const Mat &mt) {          
     return pd_c * pd + ps_c * ps + pt_c * pt;
 }
 
+/* pdf_brdf followed by eval_scattering on the same (N, wi, wo, material), as the path tracer calls them
+   (ray.cpp:1374-1405): p = pdf * rr, and f only when p > 1e-6.  The two functions build the same half vector H, the
+   same refraction normal m and the same GGX terms D(N, H), D(N, m) (the only differences are dot(N, wi) against
+   dot(wi, N): the same products, summed in the same order); here each is evaluated once -- a power function in
+   binary64 per D -- and consumed by both.  Every consumer keeps its own guard, so the values are those of the two
+   separate calls (which the unit tables on the device keep testing).  Returns p; f is written when p > 1e-6. */
+ORT_D float pdf_eval_scattering(V3 N, V3 wi, V3 wo, const Mat &mt, float rough, float dist, float rr, V3 &f) {
+    const float wi_n = dot(wi, N), wo_n = dot(wo, N);
+    const bool has_ks = len2(mt.ks) > 0.0f, has_kt = len2(mt.kt) > 0.0f;
+    /* specular lobe: shared H, wi.H, D */
+    V3 H = mk(0, 0, 0);
+    float wi_h = 0.0f, D_h = 0.0f, ps = 0.0f;
+    if (mt.ps_c > 0.0f || has_ks) {
+        H = scale(sgn(wi_n), normalize(add(wo, wi)));
+        wi_h = dot(wi, H);
+        const float denom = (4.0f * absr(wi_h));
+        const bool pdf_needs = mt.ps_c > 0.0f && !ceq(denom, 0.0f);
+        if (pdf_needs || (has_ks && wi_h > 0.0f)) D_h = ggx_d(N, H, rough);
+        if (pdf_needs) ps = D_h * absr(dot(N, H)) / denom;
+    }
+    /* transmission lobe: shared Beer indices, m, radicand, D */
+    Beer bn; bn.ni = bn.no = bn.n = 0.0f;
+    V3 m = mk(0, 0, 0);
+    float r = -1.0f, D_m = 0.0f, wi_m = 0.0f, wo_m = 0.0f, pt = ps;                /* sic: pt starts as ps */
+    if (mt.pt_c > 0.0f || has_kt) {
+        bn = beer(N, wo, mt.ior);
+        m = normalize(neg(add(scale(bn.ni, wi), scale(bn.no, wo))));
+        r = radicand(m, wo, bn.n);
+        if (!(r < 0.0f)) { /* r >= 0, or NaN: eval_scattering's else branch takes that too */
+            wi_m = dot(wi, m); wo_m = dot(wo, m);
+            D_m = ggx_d(N, m, rough);
+        }
+        if (r >= 0.0f && mt.pt_c > 0.0f) {
+            const float denom = sq(bn.no * wo_m + bn.no * wo_m);                      /* sic, ray.cpp:1054 */
+            if (!ceq(denom, 0.0f)) pt = D_m * absr(dot(N, m)) * sq(bn.no) * absr(wi_m) / denom;
+        }
+    }
+    const float pd = absr(wi_n) / kPi;
+    const float p = (mt.pd_c * pd + mt.ps_c * ps + mt.pt_c * pt) * rr;
+    if (!(p > 0.000001f)) return p;
+    /* eval_scattering, ray.cpp:936-1005 */
+    V3 Es = mk(0, 0, 0), Et = mk(0, 0, 0);
+    if (has_ks && wi_h > 0.0f) {
+        V3 F = fresnel(mt.ks, wi_h);
+        float G = geom(wi, N, H, rough) * geom(wo, N, H, rough);
+        Es = scale((D_h * G) / (4.0f * absr(wi_n) * absr(wo_n)), F);
+    }
+    if (has_kt) {
+        V3 At = mk(1, 1, 1);
+        if (wo_n < 0) {                                                           /* sic: logf(0) = -inf is relied on */
+            At.x = ort_powf(kEuler, dist * ort_logf(mt.kt.x));
+            At.y = ort_powf(kEuler, dist * ort_logf(mt.kt.y));
+            At.z = ort_powf(kEuler, dist * ort_logf(mt.kt.z));
+        }
+        if (r < 0.0f) {
+            if (has_ks) Et = had(At, Es);
+        } else {
+            V3 F = sub(mk(1, 1, 1), fresnel(mt.ks, wi_m));
+            float G = geom(wi, N, m, rough) * geom(wo, N, m, rough);
+            float denom = (absr(wi_n) * absr(wo_n) * sq(bn.ni * wi_m + bn.no * wo_m));
+            if (!ceq(denom, 0.0f)) {
+                V3 nom = scale(D_m * G * absr(wi_m) * absr(wo_m) * sq(bn.no), F);
+                Et = had(At, divs(nom, denom));
+            }
+        }
+    }
+    f = scale(absr(wi_n), add(add(mt.ed, Es), Et));
+    return p;
+}
+
 /* sample_lobe (ray.cpp:1065-1091) with cos(phi), sin(phi) supplied by the caller, so that the
    kernel can evaluate the (double-precision) sine/cosine once for lanes in different states */
 /* Nn = normalize(N) (ray.cpp:1069) is evaluated by the caller */

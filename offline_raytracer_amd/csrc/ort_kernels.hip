@@ -771,10 +771,16 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderHot &rv, const float4 *t
                     if (len2(m.kd) > 0.0f) P.weight = had(P.weight, m.kd); /* ray.cpp:1267-1270 */
                 } else {
                     /* ray.cpp:1374-1405: pdf and BSDF with the NEW surface's normal and material, the OLD wo (sic) */
-                    float p = pdf_brdf<DIFFUSE>(n, P.dir, P.wo, kRoughness, m) * rv.rr;
-                    if (p > 0.000001f) {
-                        V3 f = eval_scattering<DIFFUSE>(n, P.dir, P.wo, m, kRoughness, h.best_t);
-                        P.weight = had(divs(f, p), P.weight);
+                    if (DIFFUSE) {
+                        float p = pdf_brdf<true>(n, P.dir, P.wo, kRoughness, m) * rv.rr;
+                        if (p > 0.000001f) {
+                            V3 f = eval_scattering<true>(n, P.dir, P.wo, m, kRoughness, h.best_t);
+                            P.weight = had(divs(f, p), P.weight);
+                        }
+                    } else { /* all lobes: the two calls fused, their common terms evaluated once (ort_device.h) */
+                        V3 f = mk(0, 0, 0);
+                        const float p = pdf_eval_scattering(n, P.dir, P.wo, m, kRoughness, h.best_t, rv.rr, f);
+                        if (p > 0.000001f) P.weight = had(divs(f, p), P.weight);
                     }
                     P.wo = neg(P.dir);
                 }

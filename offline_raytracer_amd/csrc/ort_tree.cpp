@@ -21,7 +21,8 @@
 namespace ort {
 
 namespace {
-constexpr float kPrologueBudget = 10.0f; /* analytic shapes worth up to this many box tests are tested outright (see build_tree) */
+constexpr float kPrologueBudget = 14.0f; /* analytic shapes worth up to this many box tests are tested outright (see build_tree); 10 -> 14 in round 2: the three
+                                            large spheres of c2_analytic and testscene join their boxes, +5 % on both; the small scenes of the reference sit at 8.5 */
 
 struct Box3 {
     float lo[3], hi[3];

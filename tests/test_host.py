@@ -173,7 +173,7 @@ def test_reference_compatible_octree_counts(manifest, load_scene, name):
 def test_fast_tree_shape(load_scene):
     ti = load_scene("c3_bunny_room").tree_info()
     assert ti["prologue_prims"] == 8  # six room slabs, the table, the light: tested outright, not in the tree
-    assert load_scene("testscene").tree_info()["prologue_prims"] == 9  # its nine boxes; spheres and cylinders stay in the tree
+    assert load_scene("testscene").tree_info()["prologue_prims"] == 12  # its nine boxes and three largest spheres; the rest stays in the tree
     assert ti["leaf_count"] == ti["node_count"] + 1  # binary tree with leaves encoded in child words
     assert ti["max_leaf_prims"] <= 16
     assert ti["max_depth"] <= 60  # kTreeDepthBudget (ort_scene.h): the kernels' smallest stack, 20 LDS + 40 scratch entries
