@@ -205,6 +205,23 @@ def main():
         params = sharded.params(args.spp, args.seed, args.policy, chunk=chunk)
     else:
         params = api.Scene.params(W, H, args.spp, args.seed, args.policy, chunk=chunk, shard=(rank, world))
+    if sharded is not None and world > 1:
+        # probe: one small packed render + the C++ gather, before anything is timed.  If it fails on any rank (an RCCL
+        # error the communicator's creation did not show), every rank switches to the torch.distributed gather together.
+        probe_err = ""
+        try:
+            sharded.render(sharded.params(1, args.seed, "pixel"), stream=stream, want_stats=True)
+            sharded.gather(stream=stream)
+            torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001
+            probe_err = str(e)[:120] or "error"
+        ok = torch.tensor([0 if probe_err else 1], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            sharded = None
+            gather_impl = "torch.distributed.gather of packed blocks (C++ RCCL gather failed in the probe step: %s)" % (probe_err or "on another rank")
+            fb = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+            params = api.Scene.params(W, H, args.spp, args.seed, args.policy, chunk=chunk, shard=(rank, world))
 
     def step(want_stats=False):
         if sharded is not None:
