@@ -9,6 +9,7 @@ from offline_raytracer_amd import api
 import oracle_lib
 import test_gpu_parity as T
 
+COUNTERS = os.environ.get("STRESS_COUNTERS", "1") != "0"  # 0: the production kernel flavours (no work counters; ORT_EXCHANGE=1 forces the exchange loop)
 n_random = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 budget = float(sys.argv[2]) if len(sys.argv) > 2 else 240.0
 t_start = time.time()
@@ -19,7 +20,7 @@ def check(tag, scene, w, h, spp, seed, policy, chunk, csg):
     global bad
     rr = (0.8, 0.8, 0.8, 0.5, 0.95)[seed % 5]  # the reference's literal mostly; the parameter's range sometimes
     tag = tag if rr == 0.8 else "%s rr%.2f" % (tag, rr)
-    img, st = scene.render(w, h, spp, seed, policy, chunk=chunk, counters=True, rr=rr)
+    img, st = scene.render(w, h, spp, seed, policy, chunk=chunk, counters=COUNTERS, rr=rr)
     ref, ost = oracle_lib.OracleScene(scene.flatten(w, h), with_reference_csg=csg).render(w, h, spp, seed, policy, chunk=max(chunk, 1), rr=rr, threads=16)
     diff = int((img.view("<u4") != ref.view("<u4")).any(axis=2).sum())
     bad += diff != 0
