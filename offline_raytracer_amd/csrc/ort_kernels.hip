@@ -309,6 +309,12 @@ struct Prof { unsigned long long t = 0; bool on = false; };
    128-register cap, so telling it that these paths are rare moves the spills there: +4.4 % on the bunny room.  (Hints on
    ties, deep stacks and the once-per-job blocks were neutral or harmful and are not kept.) */
 #define ORT_RARE(x) __builtin_expect(!!(x), 0)
+#if defined(ORT_HOST_SIM) && defined(ORT_CHAIN_STATS) /* tools/host_sim: why rays leave the fast path */
+extern unsigned long long g_cs[4][16];
+#define ORT_STAT(row, col) (g_cs[row][col]++)
+#else
+#define ORT_STAT(row, col) ((void)0)
+#endif
 constexpr uint32_t kNoPrim = 0xffffffffu;
 constexpr uint32_t kTraversalDone = 0xffffffffu; /* == EMPTY_CHILD: a leaf word no tree contains */
 
@@ -529,8 +535,8 @@ ORT_D int chain_verdict(const SceneView &sv, uint32_t word, V3 org, V3 inv_d, fl
         }
     }
 #if defined(ORT_HOST_SIM) && defined(ORT_CHAIN_STATS)
-    { extern unsigned long long g_cs[4][16]; int jj = -1; for (int32_t i = (int32_t)len - 1; i >= 1; --i) if (!in_rect_half_open(sv.chain_boxes[2u*(first+i)], sv.chain_boxes[2u*(first+i)+1u], org)) { jj = (int)len - 1 - i; break; }
-      g_cs[0][len]++; g_cs[1][jj < 0 ? 15 : jj]++; g_cs[2][(word >> 0) == 0 ? 0 : 1]++; }
+    { int jj = -1; for (int32_t i = (int32_t)len - 1; i >= 1; --i) if (!in_rect_half_open(sv.chain_boxes[2u*(first+i)], sv.chain_boxes[2u*(first+i)+1u], org)) { jj = (int)len - 1 - i; break; }
+      g_cs[0][len]++; g_cs[1][jj < 0 ? 15 : jj]++; }
 #endif
     /* found: an ancestor that does not contain the origin must be entered at t >= 1e-6.  Then, and when every
        ancestor contains the origin, the leaf box decides the rest (origin inside it, or the bounds on its entry
@@ -684,6 +690,129 @@ ORT_D void prologue_tests(const SceneView &sv, const float4 *tab, V3 org, V3 dir
         test_prim<COUNTERS, false, false, TABS>(sv, PRIM_CYL, i, org, dir, inv_d, h.best_t, h.hit_n, h.hit_prim, h.phantom_t, h.runner_t, c.tris, c.analytic, excl, pc + 4u * i);
 }
 
+#ifndef ORT_HOST_SIM
+/* ---- the same walk, by the wave -------------------------------------------------------------------------------
+ * One lane's ray (lane `leader`), walked by all the lanes that are active with it (the others of resolve_hit's callers:
+ * any subset, at least the leader).  The order-dependent part of raycast_bvh is "best at that moment": a node's records
+ * are tested against the best so far, its children are admitted against the best after its records, nodes are taken in
+ * queue order.  Nodes are still taken one at a time, in order; what the lanes share is the work inside a node:
+ *   records: one per lane, each against the best so far; the sequential rule (take when t < best, strictly) ends with
+ *            the smallest t, the earliest record among equals -- picked here from the lanes that would take theirs;
+ *   children: one per lane, all eight against the same best (nothing changes it between them); the admitted ones are
+ *            appended in slot order by the leader lane, which is also the only lane that reads the queue (program
+ *            order of ONE thread keeps its stores and loads of the queue coherent).
+ * A node then costs about four dependent round trips instead of one per record and per child: on the 1M-triangle
+ * scene the walks took 10 % of the launch (one lane walking, 63 waiting) before this. */
+ORT_D float wave_bcast(float v, int lane) { return om_bits_f32((uint32_t)__builtin_amdgcn_readlane((int)om_f32_bits(v), lane)); }
+ORT_D uint32_t wave_bcast(uint32_t v, int lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, lane); }
+ORT_D uint32_t rank_in(unsigned long long mask) { /* set bits of mask below this lane */
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+template <bool COUNTERS>
+ORT_D bool ref_raycast_bfs_wave(const SceneView &sv, const int leader, V3 org_l, V3 dir_l, V3 inv_l, uint32_t *queue, float &out_t, V3 &out_n,
+                                uint32_t &out_prim, unsigned long long &c_nodes, unsigned long long &c_tris, unsigned long long &c_analytic) {
+    /* the leader's ray, in VECTOR registers of every lane (the empty asm hides their uniformity: as scalars they would
+       crowd the scalar register file, whose spills land in the hot code around this rare region) */
+    V3 org = mk(wave_bcast(org_l.x, leader), wave_bcast(org_l.y, leader), wave_bcast(org_l.z, leader));
+    V3 dir = mk(wave_bcast(dir_l.x, leader), wave_bcast(dir_l.y, leader), wave_bcast(dir_l.z, leader));
+    V3 inv_d = mk(wave_bcast(inv_l.x, leader), wave_bcast(inv_l.y, leader), wave_bcast(inv_l.z, leader));
+    asm volatile("" : "+v"(org.x), "+v"(org.y), "+v"(org.z), "+v"(dir.x), "+v"(dir.y), "+v"(dir.z), "+v"(inv_d.x), "+v"(inv_d.y), "+v"(inv_d.z));
+    const unsigned long long active = __ballot(true);
+    const uint32_t n_active = (uint32_t)__popcll(active), rank = rank_in(active);
+    const bool is_leader = ORT_LANE() == leader;
+    /* wave-uniform state of the walk */
+    float best_t = 3.402823466e+38f;
+    int win_lane = -1;            /* the lane that holds the best hit's normal and primitive (keep_*) */
+    V3 keep_n = mk(0, 0, 0);
+    uint32_t keep_prim = kNoPrim;
+    uint32_t head = 0, tail = 1;
+    bool ok = true;
+    const uint32_t cap = sv.cold->bfs_queue_cap;
+    if (is_leader) queue[0] = 0;
+    while (head != tail) {
+        uint32_t node_v = 0;
+        if (is_leader) node_v = queue[head];
+        const uint32_t node = wave_bcast(node_v, leader);
+        head++;
+        const float4 *np = sv.cold->ref_nodes + 3u * node;
+        const float4 a = np[0], b = np[1], c = np[2];
+        const int32_t first_child = (int32_t)om_f32_bits(a.w);
+        const uint32_t rec_first = om_f32_bits(b.w), rec_count = om_f32_bits(c.x);
+        for (uint32_t r0 = 0; r0 < rec_count; r0 += n_active) {
+            float t = best_t, unused = 0;
+            V3 n = mk(0, 0, 0);
+            uint32_t prim = kNoPrim;
+            if (r0 + rank < rec_count) {
+                const uint32_t rec = sv.cold->ref_recs[rec_first + r0 + rank];
+                test_prim<COUNTERS, true>(sv, rec >> 28, rec & 0x00ffffffu, org, dir, inv_d, t, n, prim, unused, unused, c_tris, c_analytic);
+            }
+            /* the lanes that would take their record: the smallest distance wins, the lowest lane (= earliest record) among equals */
+            unsigned long long takers = __ballot(prim != kNoPrim);
+            if (takers != 0ull) {
+                int w = -1;
+                float m = 0.0f;
+                while (takers != 0ull) {
+                    const int j = __ffsll(takers) - 1;
+                    takers &= takers - 1ull;
+                    const float tj = wave_bcast(t, j);
+                    if (w < 0 || tj < m) { m = tj; w = j; }
+                }
+                best_t = m;
+                win_lane = w;
+                if (ORT_LANE() == w) { keep_n = n; keep_prim = prim; }
+            }
+        }
+        if (first_child >= 0) {
+            for (uint32_t k0 = 0; k0 < 8u; k0 += n_active) {
+                const uint32_t k = k0 + rank;
+                bool add = false;
+                if (k < 8u) {
+                    const float4 *cp = sv.cold->ref_nodes + 3u * ((uint32_t)first_child + k);
+                    const float4 ca = cp[0], cb = cp[1], cc = cp[2];
+                    const uint32_t flags = om_f32_bits(cc.y);
+                    const bool leaf_with_records = (flags & 3u) == 3u;
+                    const bool has_children = (int32_t)om_f32_bits(ca.w) >= 0;
+                    if (leaf_with_records || has_children) {
+                        const V3 lo = mk(ca.x, ca.y, ca.z), hi = mk(cb.x, cb.y, cb.z);
+                        add = (org.x >= lo.x && org.x < hi.x) && (org.y >= lo.y && org.y < hi.y) && (org.z >= lo.z && org.z < hi.z);
+                        if (!add) {
+                            const float t = hit_aab_t(lo, hi, org, inv_d);
+                            if (COUNTERS) c_nodes++;
+                            add = (t >= kHitTMin && t < best_t);
+                        }
+                    }
+                }
+                const unsigned long long admitted = __ballot(add);
+                const uint32_t n_add = (uint32_t)__popcll(admitted);
+                if (is_leader) { /* in lane order = slot order */
+                    unsigned long long m2 = admitted;
+                    uint32_t at = tail;
+                    while (m2 != 0ull) {
+                        const int j = __ffsll(m2) - 1;
+                        m2 &= m2 - 1ull;
+                        const uint32_t kk = k0 + (uint32_t)__popcll(active & ((1ull << j) - 1ull));
+                        if (at < cap) queue[at++] = (uint32_t)first_child + kk;
+                    }
+                }
+                if (tail + n_add > cap) { ok = false; tail = cap; } else tail += n_add;
+            }
+        }
+    }
+    V3 hit_n = mk(0, 0, 0);
+    uint32_t hit_prim = kNoPrim;
+    if (win_lane >= 0) {
+        hit_n = mk(wave_bcast(keep_n.x, win_lane), wave_bcast(keep_n.y, win_lane), wave_bcast(keep_n.z, win_lane));
+        hit_prim = wave_bcast(keep_prim, win_lane);
+    }
+    if (is_leader) {
+        ORT_COUNT(sv.cold->fallback_counters + kDiagFallback, (unsigned long long)tail);
+        out_t = best_t; out_n = hit_n; out_prim = hit_prim;
+    }
+    return ok;
+}
+#endif /* !ORT_HOST_SIM */
+
 /* the exact answer: raycast_bvh emulated literally on the reference-compatible octree.  Rare.  The lanes of a
    wave that need it take turns (wave-uniform loop over the ballot), so a wave never has more than one lane
    holding or waiting for a queue of the pool: a waiting lane can only wait for holders in other waves, which
@@ -691,26 +820,39 @@ ORT_D void prologue_tests(const SceneView &sv, const float4 *tab, V3 org, V3 dir
    contents across holders on different XCDs (each XCD has its own L2). */
 template <bool COUNTERS>
 ORT_D void recast_exactly(const SceneView &sv, bool need, V3 org, V3 dir, V3 inv_d, uint32_t lane_id, HitState &h, Counters &c) {
+#ifdef ORT_MEASURE_NO_RECAST /* developer measurement only (wrong images): what the exact fallback costs, by leaving it out */
+    return;
+#endif
     unsigned long long pending = ORT_BALLOT(need);
     while (ORT_RARE(pending != 0ull)) {
         const int leader = ORT_FFS64(pending) - 1;
+        uint32_t slot = 0;
         if (ORT_LANE() == leader) {
             ORT_COUNT(sv.cold->fallback_counters, 1ull); /* straight to memory, no register kept across the loop */
             /* a queue of the pool: look before trying (a plain load does not serialise in L2 the way an atomic on a
                contended line does) and back off between looks.  Without the back-off the lanes that wait slow the
                breadth-first walks that hold the queues down (every load of theirs queues up behind the atomics), which
                makes more lanes wait: on a long launch over a 1M-triangle scene that feedback halved the throughput */
-            uint32_t slot = ((lane_id * 2654435761u) >> 8) % sv.cold->bfs_queue_count;
+            slot = ((lane_id * 2654435761u) >> 8) % sv.cold->bfs_queue_count;
             while (ORT_PEEK(sv.cold->bfs_locks + slot * kBfsLockStride) != 0u || !ORT_TRY_LOCK(sv.cold->bfs_locks + slot * kBfsLockStride)) {
                 ORT_COUNT(sv.cold->fallback_counters + kDiagFallback + 2, 1ull); /* diagnostics (ORT_DEBUG_FALLBACK): busy queues met */
                 slot = (slot + 1u) % sv.cold->bfs_queue_count;
                 ORT_BACKOFF();
             }
-            ORT_FENCE();
-            if (!ref_raycast_bfs<COUNTERS>(sv, org, dir, inv_d, sv.cold->bfs_pool + (size_t)slot * sv.cold->bfs_queue_cap, h.best_t, h.hit_n,
-                                           h.hit_prim, c.nodes, c.tris, c.analytic))
-                ORT_COUNT(sv.cold->fallback_counters + 1, 1ull);
-            ORT_FENCE();
+        }
+        ORT_FENCE();
+#ifdef ORT_HOST_SIM
+        const bool ok = ref_raycast_bfs<COUNTERS>(sv, org, dir, inv_d, sv.cold->bfs_pool + (size_t)slot * sv.cold->bfs_queue_cap, h.best_t, h.hit_n,
+                                                  h.hit_prim, c.nodes, c.tris, c.analytic);
+#else
+        /* the lanes that are here with the leader walk its ray together (ref_raycast_bfs_wave) */
+        slot = wave_bcast(slot, leader);
+        const bool ok = ref_raycast_bfs_wave<COUNTERS>(sv, leader, org, dir, inv_d, sv.cold->bfs_pool + (size_t)slot * sv.cold->bfs_queue_cap, h.best_t, h.hit_n,
+                                                       h.hit_prim, c.nodes, c.tris, c.analytic);
+#endif
+        ORT_FENCE();
+        if (ORT_LANE() == leader) {
+            if (!ok) ORT_COUNT(sv.cold->fallback_counters + 1, 1ull);
             ORT_UNLOCK(sv.cold->bfs_locks + slot * kBfsLockStride);
         }
         pending &= pending - 1ull;
@@ -1129,11 +1271,13 @@ ORT_D void resolve_hit(const SceneView &sv, const float4 *tab, V3 org, V3 dir, V
     if (!ORT_RARE(recast)) {
         if (ORT_RARE(h.phantom_t <= h.best_t)) {
             recast = true;
+            ORT_STAT(2, 1);
         } else if (h.hit_prim != kNoPrim) {
             float gap = 0.0f;
             const int verdict = chain_verdict(sv, word, org, inv_d, h.best_t, fminf(h.runner_t, h.phantom_t), gap);
             if (ORT_RARE(verdict != CH_ADMIT)) {
                 stale = true;
+                ORT_STAT(3, verdict == CH_REJECT ? 0 : 1); ORT_STAT(3, 4 + (int)(h.hit_prim >> 28));
                 ORT_COUNT(sv.cold->fallback_counters + kDiagFallback + 1, 1ull); /* diagnostics (ORT_DEBUG_FALLBACK): re-traversals */
                 /* W waits in the lane's (idle) traversal-stack slots of LDS, not in registers */
                 const uint32_t w_prim = h.hit_prim;
@@ -1151,6 +1295,7 @@ ORT_D void resolve_hit(const SceneView &sv, const float4 *tab, V3 org, V3 dir, V
                 if (verdict == CH_UNKNOWN) {
                     if (h.hit_prim != kNoPrim || h.phantom_t <= gap) {
                         recast = true; /* something is there: order decides */
+                        ORT_STAT(2, h.hit_prim != kNoPrim ? 2 : 6);
                     } else {           /* nothing there: W stands */
                         h.best_t = om_bits_f32(save[(LDS_ENTRIES - 1) * BLOCK]);
                         h.hit_n = mk(om_bits_f32(save[(LDS_ENTRIES - 2) * BLOCK]), om_bits_f32(save[(LDS_ENTRIES - 3) * BLOCK]),
@@ -1159,9 +1304,10 @@ ORT_D void resolve_hit(const SceneView &sv, const float4 *tab, V3 org, V3 dir, V
                     }
                 } else if (h.phantom_t <= h.best_t) {
                     recast = true;
+                    ORT_STAT(2, 3);
                 } else if (h.hit_prim != kNoPrim) {
                     float gap2 = 0.0f;
-                    if (chain_verdict(sv, sv.prim_info[info_index(sv, h.hit_prim)].chain, org, inv_d, h.best_t, fminf(h.runner_t, h.phantom_t), gap2) != CH_ADMIT) recast = true;
+                    if (chain_verdict(sv, sv.prim_info[info_index(sv, h.hit_prim)].chain, org, inv_d, h.best_t, fminf(h.runner_t, h.phantom_t), gap2) != CH_ADMIT) { recast = true; ORT_STAT(2, 4); }
                 }
             }
         }

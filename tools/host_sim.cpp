@@ -25,7 +25,8 @@ static int g_dbg_x = -1, g_dbg_y = -1; static FILE *g_ray_log;
 using namespace ort;
 #ifdef ORT_CHAIN_STATS
 namespace ort { unsigned long long g_cs[4][16]; }
-static void cs_dump() { for (int k = 0; k < 2; ++k) { fprintf(stderr, k ? "first-outside depth from top (15 = none):" : "chain len:"); for (int i = 0; i < 16; ++i) fprintf(stderr, " %llu", g_cs[k][i]); fprintf(stderr, "\n"); } }
+static void cs_dump() { static const char *nm[4] = {"chain len:", "first-outside depth from top (15 = none):", "re-cast reasons [1 phantom first, 2 unknown + hit in gap, 6 unknown + phantom in gap, 3 reject + phantom, 4 reject + second verdict]:", "first verdict [0 reject, 1 unknown; 4 + kind of W]:"};
+    for (int k = 0; k < 4; ++k) { fprintf(stderr, "%s", nm[k]); for (int i = 0; i < 16; ++i) fprintf(stderr, " %llu", g_cs[k][i]); fprintf(stderr, "\n"); } }
 #endif
 
 int main(int argc, char **argv) {
