@@ -250,6 +250,29 @@ def test_every_ray_through_the_reference_order_walk(api, oracle, gpu_scene, monk
     assert_bits_equal(img, ref, "1/16 of the rays re-cast")
 
 
+@pytest.mark.parametrize("name,n_jobs", [("c3_bunny_room", 1), ("testscene", 3), ("c5_heightfield_224", 7)])
+def test_reference_order_walk_with_few_lanes(api, oracle, gpu_scene, monkeypatch, name, n_jobs):
+    """The exact fallback is walked by the lanes that stand in resolve_hit together (ref_raycast_bfs_wave): records
+    and children of a node are dealt to them by rank.  One, three and seven jobs = that many lanes with a path: the
+    dealing wraps around (eight children over fewer lanes).  Every ray forced through the walk; image and final
+    RandomSeries states against the oracle."""
+    scene = gpu_scene(name)
+    monkeypatch.setenv("ORT_DEBUG_FORCE_FALLBACK", "0")
+    w, h = 48, 32
+    jobs = np.zeros(n_jobs, api.JOB_DTYPE)
+    for i in range(n_jobs):
+        x0, y0 = 6 * i, 4 * i
+        jobs[i] = (x0, y0, x0 + 5, y0 + 3, 1000 + 17 * i, 2 + (i % 3))
+    out = np.zeros((h, w, 3), "<f4")
+    finals, _ = scene.tiled_raytrace_batch(out, jobs)
+    ref = np.zeros((h, w, 3), "<f4")
+    osc = oracle.OracleScene(scene.flatten(w, h))
+    for i, j in enumerate(jobs):
+        _, st = osc.tiled_raytrace(ref, int(j["x0"]), int(j["y0"]), int(j["x1"]), int(j["y1"]), int(j["rng_state"]), int(j["spp"]))
+        assert finals[i] == st
+    assert_bits_equal(out, ref, name)
+
+
 @pytest.mark.parametrize("name,w,h,spp,seed,policy,chunk,x,y", [
     ("c2_analytic", 480, 270, 32, 7066, "pixel", 0, 25, 100),
     ("letters", 480, 270, 32, 7092, "chunk", 8, 8, 265),
