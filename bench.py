@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the render call (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W        (N > 1: starts its own N rank processes, see self_launch)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one full render of the workload through the C ABI (HIP persistent path-trace
@@ -11,15 +11,21 @@ bunny.ply (69 451 triangles) in a closed room, 1920x1080, 1024 spp, rr 0.8 -- on
 sharded by 8x8-pixel blocks over the N GPUs (total work fixed => "strong" scaling).
 
 Prints ONE JSON line on rank 0 with the contract fields plus
-  roofline     : the contract's figure -- algorithmic bytes (SURVEY 8d formula, exact device
-                 counters) / kernel time against the 8 TB/s HBM peak -- and, next to it, what
-                 the kernel is really bound by: `frac_divergent` (the same without the bytes of
-                 the analytic prologue, which are wave-uniform reads served from LDS, not memory
-                 traffic), `measured_hbm_gbs` / `traffic` (rocprofv3 PMC of this very kernel
-                 source, quoted only while profiles/r02_pmc_stamp.json carries the hash of the
-                 kernel sources that are being run), `lanes_active` and `valu_issue_frac` (same
-                 stamp).  The path is bound by VALU issue at ~50 % lane utilisation and by memory
-                 latency; measured HBM traffic is ~1 % of the peak.
+  roofline     : what bounds the kernel is VALU issue at partial lane utilisation (and the memory
+                 latency behind it), not HBM bandwidth, so the headline figure is
+                   bound "valu": achieved = useful vector lane-operations per second
+                                 = SQ_INSTS_VALU x 64 x lanes_active / kernel time  (PMC stamp of THIS
+                                 kernel source and workload, profiles/*pmc_stamp*.json; kernel time
+                                 live from HIP events), peak = 78.6 T lane-op/s (157.3 TFLOP/s f32
+                                 vector / 2), frac = achieved / peak.
+                 The memory side stays in `hbm`: SURVEY 8d's algorithmic bytes from exact device
+                 counters WITHOUT the analytic prologue's records (wave-uniform reads served from
+                 the LDS tables, not memory traffic) against the 8 TB/s peak (`frac`), the PMC-measured
+                 HBM bytes/s (`measured_gbs`; with the ray exchange on about 8 % of the peak, mostly
+                 the parking traffic of the stashes), and 8d's figure as written (`contract_frac`,
+                 saturated: kept for continuity only).  Without a stamp that matches the kernel
+                 sources and the workload the line falls back to bound "hbm" on the divergent bytes
+                 and says so.
   cpu_baseline : the reference's own code (oracle/_ref, kind "reference") or the oracle
                  (kind "port") timed on this host's cores on a bounded sample; N=1 only.
 
@@ -37,6 +43,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
+VALU_PEAK_TLANEOPS = 78.65  # same guide: 157.3 TFLOP/s f32 vector = 256 CUs x 128 lanes x 2.4 GHz x 2 flop -> lane-operations / 2
 
 
 def parse_args():
@@ -54,7 +61,65 @@ def parse_args():
                     help="seeding policy = the caller side of the reference call (include/ort.h); tile32 is main()'s schedule")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-spp", type=int, default=96)
+    ap.add_argument("--strict-gather", action="store_true",
+                    help="N > 1: fail instead of moving the blocks with torch.distributed when the C++ RCCL gather cannot be used")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="start the ranks, meet over the process group (gloo on a machine without a GPU), print one line, exit: "
+                         "exercises the launch path without rendering")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` started as ONE plain process: start N rank processes of this script (one per GPU,
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as torch.distributed.run would set them), relay rank 0's JSON line,
+    fail if any rank fails.  The parent never touches HIP or torch -- the ranks are CHILD processes started before
+    anything here could have initialised the GPU, never an exec of this process.  Counterpart in the reference:
+    main() starting its own worker threads (macos_main.mm:565-598)."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    pending = set(range(args.gpus))
+    while pending and rc == 0:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is not None:
+                pending.discard(r)
+                if code != 0:
+                    rc = code if code > 0 else 1
+                    sys.stderr.write("bench.py: rank %d exited with code %d\n" % (r, code))
+        if pending and rc == 0:
+            time.sleep(0.05)
+    if rc != 0:  # a dead rank leaves the others waiting in a collective: end exactly the processes started here
+        for r in pending:
+            procs[r].terminate()
+        for r in pending:
+            try:
+                procs[r].wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+    # ONE JSON line on stdout: anything else rank 0's libraries wrote there (gloo prints its connection banner to stdout)
+    # goes to stderr
+    lines = procs[0].stdout.read().decode().splitlines()
+    json_lines = [ln for ln in lines if ln.startswith("{")]
+    for ln in lines:
+        if not ln.startswith("{"):
+            sys.stderr.write(ln + "\n")
+    if rc == 0 and len(json_lines) != 1:
+        sys.stderr.write("bench.py: rank 0 printed %d JSON lines, expected one\n" % len(json_lines))
+        rc = 1
+    for ln in json_lines:
+        sys.stdout.write(ln + "\n")
+    sys.stdout.flush()
+    sys.exit(rc)
 
 
 def cpu_baseline(args, scene_path):
@@ -124,30 +189,62 @@ def kernel_source_hash():
 
 
 def pmc_stamp(workload_key):
-    """profiles/r02_pmc_stamp.json (tools/make_pmc_stamp.py, from a rocprofv3 --pmc run of this workload):
-    returned only if it was measured on the kernel sources that are in the tree now."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_stamp.json")
-    try:
-        st = json.load(open(path))
-    except Exception:
-        return None
-    if st.get("kernel_hash") != kernel_source_hash() or st.get("workload_key") != workload_key:
-        return None
-    return st
+    """The PMC stamp of this workload (profiles/*pmc_stamp*.json, written by tools/make_pmc_stamp.py from a
+    rocprofv3 --pmc run of the same render): returned only if it was measured on the kernel sources that are in
+    the tree now."""
+    import glob
+    want = kernel_source_hash()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_stamp*.json")), reverse=True):
+        try:
+            st = json.load(open(path))
+        except Exception:
+            continue
+        if st.get("kernel_hash") == want and st.get("workload_key") == workload_key:
+            st["file"] = os.path.relpath(path, ROOT)
+            return st
+    return None
 
 
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    launch_mode = ("torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else
+                   ("self-launched rank processes" if "WORLD_SIZE" in os.environ else "single process"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)  # a plain `python bench.py --gpus N`: this process only starts and watches the ranks
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
         args.gpus = world
 
     import torch
     import torch.distributed as dist
+
+    if os.environ.get("ORT_BENCH_TEST_FAIL_RANK") == str(rank):
+        sys.exit(3)  # tests/test_bench_launch.py: a rank that dies must fail the whole launch, promptly
+    if args.rendezvous_only:
+        # the launch path alone: every rank meets the others over the process group (what the bench's barrier, max-over-
+        # ranks timing and id broadcast ride on) and rank 0 prints one line.  gloo where there is no GPU (CPU tests).
+        on_gpu = torch.cuda.is_available() and os.environ.get("ORT_BENCH_SHARE_GPU") != "1" and torch.cuda.device_count() >= world
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if on_gpu:
+                torch.cuda.set_device(local_rank)
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            t = torch.tensor([float(rank + 1)], device=torch.device("cuda", local_rank) if on_gpu else torch.device("cpu"))
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            total = float(t.item())
+            dist.barrier()
+            dist.destroy_process_group()
+        else:
+            total = 1.0
+        if rank == 0:
+            print(json.dumps({"rendezvous": "ok", "world": world, "backend": "nccl" if (on_gpu and world > 1) else "gloo",
+                              "rank_sum": total, "expected": world * (world + 1) / 2.0}), flush=True)
+        return
+
     from offline_raytracer_amd import api, dist as odist
 
     if not torch.cuda.is_available() or api.device_count() < 1:
@@ -200,6 +297,11 @@ def main():
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if int(ok.item()) == 0:
                 sharded = None
+            if sharded is None and not share_gpu:
+                if args.strict_gather:
+                    sys.exit("bench.py --strict-gather: the C++ RCCL gather is unavailable (%s)" % gather_impl)
+                if rank == 0:
+                    sys.stderr.write("bench.py: WARNING: %s\n" % gather_impl)
     fb = sharded.full if (sharded is not None and rank == 0) else torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
     if sharded is not None:
         params = sharded.params(args.spp, args.seed, args.policy, chunk=chunk)
@@ -220,6 +322,10 @@ def main():
         if int(ok.item()) == 0:
             sharded = None
             gather_impl = "torch.distributed.gather of packed blocks (C++ RCCL gather failed in the probe step: %s)" % (probe_err or "on another rank")
+            if args.strict_gather:
+                sys.exit("bench.py --strict-gather: %s" % gather_impl)
+            if rank == 0:
+                sys.stderr.write("bench.py: WARNING: %s\n" % gather_impl)
             fb = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
             params = api.Scene.params(W, H, args.spp, args.seed, args.policy, chunk=chunk, shard=(rank, world))
 
@@ -287,6 +393,40 @@ def main():
     achieved_divergent = bytes_per_path_divergent * my_paths / (k_ms * 1e-3) / 1e9
 
     if rank == 0:
+        k_s = k_ms * 1e-3
+        hbm = {"achieved": achieved_divergent, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved_divergent / HBM_PEAK_GBS,
+               "bytes_per_path": bytes_per_path_divergent,
+               "what": "SURVEY 8d's algorithmic bytes from exact device counters, without the analytic prologue's records (wave-uniform reads "
+                       "served from the LDS tables), per launch / kernel time",
+               "measured_gbs": (traffic / k_s / 1e9) if traffic else None,
+               "measured_frac": (traffic / k_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
+               "l2_hit_rate": stamp.get("l2_hit_rate") if stamp else None,
+               "contract_bytes_per_path": bytes_per_path, "contract_achieved": achieved, "contract_frac": achieved / HBM_PEAK_GBS,
+               "contract_note": "8d's formula as written prices the prologue's LDS-served records as HBM bytes: saturated, kept for continuity only"}
+        if stamp and stamp.get("counters", {}).get("SQ_INSTS_VALU"):
+            # useful vector lane-operations per second: wave-level VALU instructions of one launch (PMC) x 64 lanes x the
+            # fraction of lanes that were active in them, over the kernel time measured live
+            valu_insts = float(stamp["counters"]["SQ_INSTS_VALU"])
+            useful = valu_insts * 64.0 * float(stamp["lanes_active"]) / k_s / 1e12
+            roofline = {"bound": "valu", "achieved": useful, "peak": VALU_PEAK_TLANEOPS, "unit": "Tlane-op/s", "frac": useful / VALU_PEAK_TLANEOPS,
+                        "traffic": traffic, "valu_insts_per_launch": valu_insts, "lanes_active": stamp.get("lanes_active"),
+                        "valu_issue_frac": valu_insts / k_s / (VALU_PEAK_TLANEOPS * 1e12 / 64.0),
+                        "valu_issue_frac_at_stamp": stamp.get("valu_issue_frac"),
+                        "wave_cycles_waiting_on_memory": stamp.get("wave_cycles_waiting_on_memory"),
+                        "limiter": "VALU issue at partial lane utilisation (divergence) with memory latency behind it; not HBM bandwidth"}
+        else:
+            roofline = {"bound": "hbm", "achieved": achieved_divergent, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": achieved_divergent / HBM_PEAK_GBS, "traffic": None, "lanes_active": None, "valu_issue_frac": None,
+                        "limiter": "no PMC stamp matches these kernel sources and this workload (profiles/*pmc_stamp*.json): "
+                                   "falling back to the divergent algorithmic bytes against the HBM peak"}
+        roofline.update({
+            "hbm": hbm, "frac_divergent": achieved_divergent / HBM_PEAK_GBS,
+            "pmc_stamp": ({"file": stamp.get("file"), "kernel_hash": stamp["kernel_hash"], "git_commit": stamp.get("git_commit"),
+                           "source": stamp.get("source"), "workload_key": stamp.get("workload_key")} if stamp else None),
+            "kernel_hash": kernel_source_hash(), "workload_key": workload_key,
+            "kernel": "pt_persistent", "kernel_ms": k_ms,
+            "rays_per_path": R, "node_tests_per_ray": Vn, "tri_tests_per_ray": Vt,
+            "analytic_tests_per_ray": Vp, "prologue_tests_per_ray": pro, "fallback_rays": cst["fallback_rays"]})
         line = {
             "metric": "Mpaths/s", "value": value, "unit": "Mpaths/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
@@ -298,20 +438,9 @@ def main():
                                    ("CHUNK policy chunk=%d" % args.chunk) if args.policy == "chunk" else
                                    ("TILE32 policy: main()'s 1024 tiles, one serial stream each" if args.policy == "tile32" else "PIXEL policy"), world),
                        "width": W, "height": H, "spp": args.spp, "paths_per_step": paths_per_step, "gather": gather_impl,
-                       "workspace_bytes_per_rank": api.workspace_bytes(params)},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "frac_divergent": achieved_divergent / HBM_PEAK_GBS, "bytes_per_path_divergent": bytes_per_path_divergent,
-                         "measured_hbm_gbs": (traffic / (k_ms * 1e-3) / 1e9) if traffic else None,
-                         "measured_frac": (traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                         "lanes_active": stamp.get("lanes_active") if stamp else None,
-                         "valu_issue_frac": stamp.get("valu_issue_frac") if stamp else None,
-                         "limiter": "VALU issue at partial lane utilisation + memory latency; not HBM bandwidth (scene is L2 / Infinity-Cache resident)",
-                         "pmc_stamp": ({"kernel_hash": stamp["kernel_hash"], "git_commit": stamp.get("git_commit"), "source": stamp.get("source")} if stamp else None),
-                         "kernel_hash": kernel_source_hash(),
-                         "kernel": "pt_persistent", "kernel_ms": k_ms, "bytes_per_path": bytes_per_path,
-                         "rays_per_path": R, "node_tests_per_ray": Vn, "tri_tests_per_ray": Vt,
-                         "analytic_tests_per_ray": Vp, "fallback_rays": cst["fallback_rays"]},
+                       "gather_fallback": bool(world > 1 and sharded is None),
+                       "launch": launch_mode, "workspace_bytes_per_rank": api.workspace_bytes(params)},
+            "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, scene_path)
