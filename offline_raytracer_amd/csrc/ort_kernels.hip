@@ -154,7 +154,25 @@ struct RenderView {
     uint32_t park_min;   /* stragglers are parked only when there are at least this many of them (fewer: they idle through one shading pass, cheaper than an exchange step) */
     uint32_t inflight_cap; /* a lane without a path starts a new job only while the wave holds fewer parked paths than this
                               (every parked path is a job in progress: the more a wave holds, the longer its tail) */
+    /* expensive-blocks-first issue of the LAST chunk (CHUNK policy, lpt_order below): u32 words in HBM,
+       [kLptHdr header][cost per local block][finished chunk-0 jobs per local block][kLptBuckets lists of my_blocks] */
+    uint32_t *lpt;
 };
+
+/* ---- the tail of a launch, and the order of the last chunk -----------------------------------------------------
+ * A job is a serial stream of `chunk` samples that only one lane can advance, so a launch ends one job length after
+ * its job counter runs dry: the lanes that drew an expensive job last (a bunny pixel costs several wall pixels) finish
+ * it alone.  Measured (profiles/r03_scaling_proxy.json): 13 ms on the 61 ms an 8-way shard of the headline frame needs,
+ * proportional to the job length.  The job space is [chunk][block][pixel]; every chunk of a pixel costs about the same,
+ * so chunk 0 -- finished long before the last chunk is issued -- tells what each 8x8 block costs (bounces counted per
+ * job in LDS, summed per block), and the last chunk's blocks are then issued most expensive first (longest processing
+ * time first): the jobs drawn last are the cheapest ones.  Which lane renders which job, and when, cannot change a bit
+ * of the image (seeds belong to jobs); the permutation is a bijection whatever the costs say, because every block is
+ * entered into exactly one bucket list exactly once (by the lane that finishes its 64th chunk-0 job).
+ * Header words: */
+constexpr uint32_t kLptBuckets = 64;
+enum : uint32_t { LPT_BLOCKS_DONE = 0, LPT_READY = 1, LPT_MODE = 2, LPT_COUNT = 8, LPT_START = 8 + kLptBuckets, kLptHdr = 8 + 2 * kLptBuckets + 8 };
+enum : uint32_t { LPT_UNDECIDED = 0, LPT_SORTED = 1, LPT_NATURAL = 2 };
 
 /* What the kernels receive by value: the handful of render parameters every ray reads; everything else stays in the
    RenderView in HBM behind `c` (job decoding, pixel addresses, stashes: read once per job or per pixel).  By value the
@@ -182,8 +200,51 @@ struct WfView {
     unsigned long long *active; /* rays produced by the last counted shade launch */
 };
 
+/* Developer knobs (none changes a result).  The environment is read ONCE, when the scene is uploaded
+   (ort_scene_upload); ORT_KNOBS_LIVE=1 -- tests and tuning sweeps that flip a knob between two renders of one uploaded
+   scene -- reads it again at every render.  -1 = not set: the launch policy decides. */
+struct Knobs {
+    uint32_t force_fallback_mask = 0xffffffffu; /* ORT_DEBUG_FORCE_FALLBACK */
+    bool debug_util = false, debug_fallback = false; /* ORT_DEBUG_UTIL, ORT_DEBUG_FALLBACK */
+    int cache_resident = -1;   /* ORT_CACHE_RESIDENT */
+    int refill_below = -1, descend_below = -1; /* ORT_REFILL_BELOW, ORT_DESCEND_BELOW */
+    bool wavefront = false;    /* ORT_MODE=wavefront */
+    bool general_kernel = false; /* ORT_KERNEL=general */
+    int lds_tables = -1;       /* ORT_LDS_TABLES */
+    int exchange = -1;         /* ORT_EXCHANGE */
+    int long_min = -1, long_refill = -1, inflight_cap = -1, park_min = -1; /* ORT_LONG_MIN, ORT_LONG_REFILL, ORT_INFLIGHT_CAP, ORT_PARK_MIN */
+    int lpt = -1;              /* ORT_LPT: expensive-blocks-first issue of the last chunk */
+    int blocks_per_cu = -1;    /* ORT_BLOCKS_PER_CU (takes effect at upload) */
+};
+static int env_int(const char *name, int unset = -1) {
+    const char *e = getenv(name);
+    return e ? atoi(e) : unset;
+}
+static Knobs read_knobs() {
+    Knobs k;
+    const char *e;
+    if ((e = getenv("ORT_DEBUG_FORCE_FALLBACK"))) k.force_fallback_mask = (uint32_t)strtoul(e, nullptr, 0);
+    k.debug_util = getenv("ORT_DEBUG_UTIL") != nullptr;
+    k.debug_fallback = getenv("ORT_DEBUG_FALLBACK") != nullptr;
+    k.cache_resident = env_int("ORT_CACHE_RESIDENT");
+    k.refill_below = env_int("ORT_REFILL_BELOW");
+    k.descend_below = env_int("ORT_DESCEND_BELOW");
+    k.wavefront = (e = getenv("ORT_MODE")) && strcmp(e, "wavefront") == 0;
+    k.general_kernel = (e = getenv("ORT_KERNEL")) && strcmp(e, "general") == 0;
+    k.lds_tables = env_int("ORT_LDS_TABLES");
+    k.exchange = env_int("ORT_EXCHANGE");
+    k.long_min = env_int("ORT_LONG_MIN");
+    k.long_refill = env_int("ORT_LONG_REFILL");
+    k.inflight_cap = env_int("ORT_INFLIGHT_CAP");
+    k.park_min = env_int("ORT_PARK_MIN");
+    k.lpt = env_int("ORT_LPT");
+    k.blocks_per_cu = env_int("ORT_BLOCKS_PER_CU");
+    return k;
+}
+
 struct DeviceScene {
     int device = -1;
+    Knobs knobs;
     void *nodes = nullptr, *tris = nullptr, *spheres = nullptr, *boxes = nullptr, *cyls = nullptr, *materials = nullptr;
     void *prim_info = nullptr;
     uint32_t info_box = 0, info_cyl = 0, info_sphere = 0;
@@ -214,6 +275,8 @@ struct DeviceScene {
     int cu_count = 0;
     void *stash = nullptr; /* ray exchange: the waves' stashes */
     size_t stash_bytes = 0;
+    void *lpt = nullptr;   /* cost-ordered issue of the last chunk (RenderView::lpt) */
+    size_t lpt_bytes = 0;
     void *wf_mem = nullptr; /* wavefront state, carved into the WfView arrays */
     size_t wf_bytes = 0;
     unsigned long long *h_active = nullptr; /* pinned */
@@ -867,6 +930,50 @@ ORT_D V3 focal_point(const RenderHot &rv, uint32_t pxy, V3 cam_p, V3 cam_x, V3 c
     return add(cam_p, scale(focal_length, to_pixel));
 }
 
+#ifndef ORT_HOST_SIM
+ORT_D uint32_t lpt_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+ORT_D void lpt_store(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+/* a chunk-0 job of local block lb has ended (or was skipped: pixel outside the rect) with `bounces` rays cast beyond
+   its primaries.  The lane that ends the block's 64th job files the block under its cost; the lane that files the last
+   block publishes the lists. */
+ORT_D void lpt_job_done(uint32_t *lpt, uint32_t my_blocks, uint32_t per_bucket, uint32_t lb, uint32_t bounces) {
+    uint32_t *cost = lpt + kLptHdr, *done = cost + my_blocks, *lists = done + my_blocks;
+    if (bounces) atomicAdd(cost + lb, bounces);
+    if (atomicAdd(done + lb, 1u) != 63u) return;
+    uint32_t b = lpt_load(cost + lb) / per_bucket;
+    b = b < kLptBuckets ? b : kLptBuckets - 1u;
+    const uint32_t slot = atomicAdd(lpt + LPT_COUNT + b, 1u);
+    lpt_store(lists + (size_t)b * my_blocks + slot, lb);
+    __threadfence(); /* the list entry before the count of filed blocks */
+    if (atomicAdd(lpt + LPT_BLOCKS_DONE, 1u) != my_blocks - 1u) return;
+    uint32_t at = 0; /* most expensive bucket first */
+    for (uint32_t k = kLptBuckets; k-- > 0u;) {
+        lpt_store(lpt + LPT_START + k, at);
+        at += lpt_load(lpt + LPT_COUNT + k);
+    }
+    __threadfence();
+    lpt_store(lpt + LPT_READY, 1u);
+}
+/* the i-th block of the last chunk: by descending cost when the lists were complete before the first job of the last
+   chunk was decoded (decided once, by whoever decodes first: every lane must use the same order), else in natural order */
+ORT_D uint32_t lpt_order(uint32_t *lpt, uint32_t my_blocks, uint32_t i) {
+    uint32_t mode = lpt_load(lpt + LPT_MODE);
+    if (mode == LPT_UNDECIDED) {
+        const uint32_t want = lpt_load(lpt + LPT_READY) ? LPT_SORTED : LPT_NATURAL;
+        const uint32_t old = atomicCAS(lpt + LPT_MODE, (uint32_t)LPT_UNDECIDED, want);
+        mode = old != LPT_UNDECIDED ? old : want;
+    }
+    if (mode != LPT_SORTED) return i;
+    __threadfence();
+    uint32_t lb = i;
+    for (uint32_t k = 0; k < kLptBuckets; ++k) {
+        const uint32_t first = lpt_load(lpt + LPT_START + k), n = lpt_load(lpt + LPT_COUNT + k);
+        if (i >= first && i < first + n) { lb = lpt_load(lpt + kLptHdr + 2u * my_blocks + (size_t)k * my_blocks + (i - first)); break; }
+    }
+    return lb;
+}
+#endif
+
 /* Advance the lane's path state machine until it has produced the next ray (returns true; the ray
    is P.org / P.dir) or has run out of work (returns false).  On entry with P.ps == PS_HIT, h holds
    the resolved closest hit of the ray produced by the previous call. */
@@ -942,6 +1049,7 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderHot &rv, const float4 *t
                     if (is_sphere) { rng_step(P.rng); rng_step(P.rng); rng_step(P.rng); rng_step(P.rng); }
                 }
                 ORT_UTIL(sv, 6, true);
+                if (IMPLICIT && focal_cache) ((uint32_t *)focal_cache)[3 * focal_stride] += 1u; /* this job's bounces: what its block costs (lpt_job_done) */
                 draw = sample_brdf_draw<DIFFUSE>(P.rng, kRoughness, m);
                 angle = draw.phi;
             } else {
@@ -963,6 +1071,12 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderHot &rv, const float4 *t
                 p[0] = o.x; p[1] = o.y; p[2] = o.z;
                 if (IMPLICIT) {
                     P.ps = PS_NEED_JOB; /* a one-pixel job ends with its pixel */
+#ifndef ORT_HOST_SIM
+                    if (rv.mode == JOBS_CHUNK && (P.jyp >> 16) == 0u && focal_cache) {
+                        uint32_t *lpt = rv.c->lpt;
+                        if (lpt) lpt_job_done(lpt, rv.c->my_blocks, 8u * job_spp, (uint32_t)(packed_index(rv, px, py) >> 6), ((const uint32_t *)focal_cache)[3 * focal_stride]);
+                    }
+#endif
                 } else {
                 px++;
                 if (px == (P.jxx >> 16)) { px = P.jxx & 0xffffu; py++; }
@@ -994,11 +1108,21 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderHot &rv, const float4 *t
                     unsigned long long per_chunk = (unsigned long long)rv.c->my_blocks * 64ull;
                     uint32_t k = (uint32_t)(j / per_chunk);
                     uint32_t rem = (uint32_t)(j % per_chunk);
-                    uint32_t blk = rv.c->shard_index + (rem >> 6) * rv.c->shard_count;
+                    uint32_t lb = rem >> 6; /* local block */
+#ifndef ORT_HOST_SIM
+                    uint32_t *lpt = (IMPLICIT && rv.mode == JOBS_CHUNK && focal_cache) ? rv.c->lpt : nullptr;
+                    if (lpt && k + 1u == rv.c->nchunks) lb = lpt_order(lpt, rv.c->my_blocks, lb);
+#endif
+                    uint32_t blk = rv.c->shard_index + lb * rv.c->shard_count;
                     uint32_t pin = rem & 63u;
                     int x = (int)((rv.c->block_x0 + blk % rv.c->blocks_w) * 8u + (pin & 7u));
                     int y = (int)((rv.c->block_y0 + blk / rv.c->blocks_w) * 8u + (pin >> 3));
-                    if (x < rv.c->x0 || x >= rv.c->x1 || y < rv.c->y0 || y >= rv.c->y1) continue;
+                    if (x < rv.c->x0 || x >= rv.c->x1 || y < rv.c->y0 || y >= rv.c->y1) {
+#ifndef ORT_HOST_SIM
+                        if (lpt && k == 0u) lpt_job_done(lpt, rv.c->my_blocks, 8u * rv.c->chunk, lb, 0u); /* skipped jobs count towards their block's 64 */
+#endif
+                        continue;
+                    }
                     uint32_t pix = (uint32_t)(y * rv.W + x);
                     if (!IMPLICIT) P.jxx = (uint32_t)x | ((uint32_t)(x + 1) << 16);
                     P.pxy = (uint32_t)x | ((uint32_t)y << 16);
@@ -1022,6 +1146,7 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderHot &rv, const float4 *t
                 if (focal_cache) { /* the pixel's focal point, once per pixel (persistent kernel: three floats of LDS per lane) */
                     V3 f = focal_point(rv, P.pxy, cam_p, cam_x, cam_y, cam_z, focal_length);
                     focal_cache[0] = f.x; focal_cache[focal_stride] = f.y; focal_cache[2 * focal_stride] = f.z;
+                    if (IMPLICIT) ((uint32_t *)focal_cache)[3 * focal_stride] = 0u; /* a one-pixel job starts: its bounce count */
                 }
             }
             if (P.sample == job_spp) continue; /* spp == 0: the reference's sample loop runs zero times */
@@ -1654,7 +1779,7 @@ template <bool COUNTERS, bool DIFFUSE, bool TABS, bool IMPLICIT = false>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(ORT_WAVES_PER_EU, ORT_WAVES_PER_EU)))
 pt_persistent(SceneView sv, RenderHot rv) {
     __shared__ uint32_t lds_stack[kLdsStack * kBlock];
-    __shared__ float lds_focal[3 * kBlock]; /* focal[component][lane] */
+    __shared__ float lds_focal[4 * kBlock]; /* focal[component][lane]; row 3: bounces of the lane's current job (u32) */
     __shared__ float4 lds_tab[TABS ? kTabF4 : 1];
     if (TABS) fill_tab(sv, lds_tab);
     const bool prof = COUNTERS && sv.util != nullptr && blockIdx.x < 32u;
@@ -1675,7 +1800,7 @@ template <bool COUNTERS, bool DIFFUSE>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(ORT_WAVES_PER_EU, ORT_WAVES_PER_EU)))
 pt_persistent_x(SceneView sv, RenderHot rv) {
     __shared__ uint32_t lds_stack[kLdsStack * kBlock];
-    __shared__ float lds_focal[3 * kBlock];
+    __shared__ float lds_focal[4 * kBlock];
     __shared__ float4 lds_tab[kTabF4];
     fill_tab(sv, lds_tab);
     const bool prof = COUNTERS && sv.util != nullptr && blockIdx.x < 32u;
@@ -1836,6 +1961,7 @@ void device_release(Scene *scene) {
         if (p) (void)hipFree(p);
     if (d->wf_mem) (void)hipFree(d->wf_mem);
     if (d->stash) (void)hipFree(d->stash);
+    if (d->lpt) (void)hipFree(d->lpt);
     if (d->h_active) (void)hipHostFree(d->h_active);
     if (d->ev0) (void)hipEventDestroy(d->ev0);
     if (d->ev1) (void)hipEventDestroy(d->ev1);
@@ -1929,8 +2055,8 @@ int device_upload(Scene *scene, int device, std::string *err) {
     d->cu_count = prop.multiProcessorCount;
     /* persistent grid: 4 workgroups of 256 lanes per CU */
     {
-        const char *e = getenv("ORT_BLOCKS_PER_CU"); /* tuning knob: resident workgroups per CU (4 = one wave per SIMD each) */
-        unsigned int per_cu = e ? (unsigned int)atoi(e) : 4u;
+        d->knobs = read_knobs();
+        unsigned int per_cu = d->knobs.blocks_per_cu > 0 ? (unsigned int)d->knobs.blocks_per_cu : 4u; /* resident workgroups per CU (4 = one wave per SIMD each) */
         if (per_cu < 1u || per_cu > 8u) per_cu = 4u;
         d->max_blocks = (unsigned int)(d->cu_count > 0 ? d->cu_count : 256) * per_cu;
     }
@@ -2098,10 +2224,11 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
     sv.pro_spheres = scene->tree.pro_spheres;
     sv.pro_cyls = scene->tree.pro_cyls;
     sv.chain_boxes = (const float4 *)d->chain_boxes;
-    const char *ff = getenv("ORT_DEBUG_FORCE_FALLBACK");
-    sv.force_fallback_mask = ff ? (uint32_t)strtoul(ff, nullptr, 0) : 0xffffffffu;
+    if (getenv("ORT_KNOBS_LIVE")) { const int keep = d->knobs.blocks_per_cu; d->knobs = read_knobs(); d->knobs.blocks_per_cu = keep; }
+    const Knobs &kn = d->knobs;
+    sv.force_fallback_mask = kn.force_fallback_mask;
     sv.cold = (const ORT_CONSTANT_AS SceneCold *)d->cold;
-    const bool want_util = getenv("ORT_DEBUG_UTIL") != nullptr; /* developer diagnostics, counters build only */
+    const bool want_util = kn.debug_util; /* developer diagnostics, counters build only */
     sv.util = want_util ? d->ctrl + 8 : nullptr;
     ort_camera cam;
     camera_basis(*scene, p->width, p->height, &cam);
@@ -2117,18 +2244,16 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
         /* tuning knobs; results do not depend on them.  Defaults tuned on MI355X (profiles/r01_tuning.md)
            separately for trees that stay in L2 and trees that do not */
         const size_t fast_tree_bytes = scene->tree.nodes.size() * sizeof(DevNode) + scene->tree.tris.size() * sizeof(DevTri);
-        const char *cr = getenv("ORT_CACHE_RESIDENT"); /* A/B runs: treat the tree as (not) cache-resident */
-        const bool cache_resident = cr ? atoi(cr) != 0 : fast_tree_bytes <= (size_t)(16u << 20);
+        /* ORT_CACHE_RESIDENT, A/B runs: treat the tree as (not) cache-resident */
+        const bool cache_resident = kn.cache_resident >= 0 ? kn.cache_resident != 0 : fast_tree_bytes <= (size_t)(16u << 20);
         cache_resident_tree = cache_resident;
-        const char *e = getenv("ORT_REFILL_BELOW");
-        rv.refill_below = e ? atoi(e) : (cache_resident ? 12 : 32);
+        rv.refill_below = kn.refill_below >= 0 ? kn.refill_below : (cache_resident ? 12 : 32);
         if (rv.refill_below < 1) rv.refill_below = 1;
         if (rv.refill_below > 64) rv.refill_below = 64;
-        e = getenv("ORT_DESCEND_BELOW");
         /* cache-resident trees (bunny room: 6 MB): 8, worth +10 %.  Trees that leave the 8 x 4 MB of L2 (the 1M-triangle
            scene, 86 MB): 16 and a later refill (32): the waits are longer there, so leaving the loops costs more
            (3840x2160, 256 spp: 1 272 Mpaths/s; with the small-tree values 1 100; profiles/r02_tuning.md) */
-        rv.descend_below = e ? atoi(e) : (cache_resident ? 8 : 16);
+        rv.descend_below = kn.descend_below >= 0 ? kn.descend_below : (cache_resident ? 8 : 16);
         if (rv.descend_below < 0) rv.descend_below = 0;
         if (rv.descend_below > 64) rv.descend_below = 64;
     }
@@ -2175,14 +2300,11 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
     unsigned int grid = (unsigned int)((lanes_wanted + kBlock - 1) / kBlock);
     if (grid > max_blocks) grid = max_blocks;
     if (grid == 0) grid = 1;
-    const char *mode_env = getenv("ORT_MODE"); /* "wavefront" | "persistent"; results are identical */
-    const bool wavefront = mode_env ? (strcmp(mode_env, "wavefront") == 0) : false;
-    const char *kenv = getenv("ORT_KERNEL"); /* "general" forces the all-lobes kernel (A/B runs; same results) */
-    const bool diffuse = d->diffuse_only && !(kenv && strcmp(kenv, "general") == 0);
+    const bool wavefront = kn.wavefront; /* ORT_MODE=wavefront; results are identical */
+    const bool diffuse = d->diffuse_only && !kn.general_kernel; /* ORT_KERNEL=general forces the all-lobes kernel (A/B runs; same results) */
     /* TABS: the scene's small tables all fit their LDS slots (every scene of this repository); otherwise HBM */
     const uint32_t all_tabs = TAB_PRO | TAB_LIGHTS | TAB_MATS;
-    const char *tenv = getenv("ORT_LDS_TABLES"); /* "0": read them from HBM anyway (A/B runs; same results) */
-    const bool tabs = (d->tab_flags & all_tabs) == all_tabs && !(tenv && atoi(tenv) == 0);
+    const bool tabs = (d->tab_flags & all_tabs) == all_tabs && kn.lds_tables != 0; /* ORT_LDS_TABLES=0: read them from HBM anyway (A/B runs; same results) */
     bool exch = false;
     if (!wavefront) {
         /* ray exchange (pt_lane_x): bit-identical; 60 of 64 lanes in the shading pass instead of 53 and leaf
@@ -2190,26 +2312,37 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
            (profiles/r02_tuning.md): the diffuse flavour (the all-lobes one spills too much around the exchange) on
            launches of at least 24 jobs per lane -- every parked path is a job in progress, so a wave's tail grows with
            what it has parked, which short launches and 8-way shards cannot amortise.  ORT_EXCHANGE=0 / 1 forces it. */
-        const char *xenv = getenv("ORT_EXCHANGE");
         /* ... and not for trees that leave the L2 (the 1M-triangle scene: 1 268 with it, 1 272 without) */
         const bool worth_it = diffuse && cache_resident_tree && rv.job_count >= 24ull * (unsigned long long)grid * kBlock;
-        exch = tabs && rv.mode != JOBS_EXPLICIT && (xenv ? atoi(xenv) != 0 : worth_it) && (!counters || (want_util && diffuse));
-        if (exch && !getenv("ORT_REFILL_BELOW")) rv.refill_below = 16; /* stragglers park instead of idling: leave the loop a little earlier */
+        exch = tabs && rv.mode != JOBS_EXPLICIT && (kn.exchange >= 0 ? kn.exchange != 0 : worth_it) && (!counters || (want_util && diffuse));
+        if (exch && kn.refill_below < 0) rv.refill_below = 16; /* stragglers park instead of idling: leave the loop a little earlier */
         if (exch) {
-            const char *e;
             rv.capL = 128; rv.capR = 192;
-            rv.long_min = (e = getenv("ORT_LONG_MIN")) ? (uint32_t)atoi(e) : 64u;
-            rv.long_refill = (e = getenv("ORT_LONG_REFILL")) ? (uint32_t)atoi(e) : 32u;
-            rv.inflight_cap = (e = getenv("ORT_INFLIGHT_CAP")) ? (uint32_t)atoi(e) : 64u;
-            rv.park_min = (e = getenv("ORT_PARK_MIN")) ? (uint32_t)atoi(e) : 1u;
+            rv.long_min = kn.long_min >= 0 ? (uint32_t)kn.long_min : 64u;
+            rv.long_refill = kn.long_refill >= 0 ? (uint32_t)kn.long_refill : 32u;
+            rv.inflight_cap = kn.inflight_cap >= 0 ? (uint32_t)kn.inflight_cap : 64u;
+            rv.park_min = kn.park_min >= 0 ? (uint32_t)kn.park_min : 1u;
             if (rv.long_min < 1u) rv.long_min = 1u;
             if (rv.long_min > rv.capL) rv.long_min = rv.capL;
             if (rv.long_refill > 64u) rv.long_refill = 64u;
+            /* a wave whose lanes all hold off new jobs (parked paths >= inflight_cap) must be able to start a traversal phase
+               on what it has parked (parked + tracing >= long_min), or nothing in it could ever move again */
+            if (rv.inflight_cap < rv.long_min) rv.inflight_cap = rv.long_min;
+            if (rv.inflight_cap < 1u) rv.inflight_cap = 1u;
             rv.stash_wave_f4 = (kStashVecs + (uint32_t)kLdsStack / 4u) * rv.capL + kStashVecs * rv.capR;
             const size_t need = (size_t)d->max_blocks * (kBlock / 64) * rv.stash_wave_f4 * sizeof(float4);
             if ((rc = ensure(&d->stash, &d->stash_bytes, need, err))) return rc;
             rv.stash = (float4 *)d->stash;
         }
+    }
+    /* expensive-blocks-first issue of the last chunk (lpt_order): CHUNK renders of at least four chunks, so that chunk 0,
+       whose jobs measure the blocks, is long finished when the last chunk is issued (if it is not, the kernel notices and
+       keeps the natural order).  ORT_LPT=0 switches it off (A/B runs; same image either way). */
+    if (!wavefront && rv.mode == JOBS_CHUNK && rv.nchunks >= 4u && rv.my_blocks > 0u && kn.lpt != 0) {
+        const size_t words = (size_t)kLptHdr + (size_t)(2u + kLptBuckets) * rv.my_blocks;
+        if ((rc = ensure(&d->lpt, &d->lpt_bytes, words * sizeof(uint32_t), err))) return rc;
+        ORT_HIP(hipMemsetAsync(d->lpt, 0, ((size_t)kLptHdr + 2u * (size_t)rv.my_blocks) * sizeof(uint32_t), stream));
+        rv.lpt = (uint32_t *)d->lpt;
     }
     /* the RenderView goes to HBM (pageable source: the copy is staged before the call returns); the kernels get the few
        fields every ray reads by value and a pointer to the rest */
@@ -2260,7 +2393,7 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
         ORT_HIP(hipMemcpy(&ovf, d->ctrl + 7, sizeof(ovf), hipMemcpyDeviceToHost));
         if (ovf) { *err = "reference-order fallback queue overflowed"; return ORT_ERR_UNSUPPORTED; }
     }
-    if (stats && getenv("ORT_DEBUG_FALLBACK")) { /* developer diagnostics */
+    if (stats && kn.debug_fallback) { /* developer diagnostics */
         unsigned long long fb[2], dg[3];
         ORT_HIP(hipMemcpy(fb, d->ctrl + 6, sizeof(fb), hipMemcpyDeviceToHost));
         ORT_HIP(hipMemcpy(dg, d->ctrl + 6 + kDiagFallback, sizeof(dg), hipMemcpyDeviceToHost));

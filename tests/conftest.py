@@ -10,6 +10,10 @@ ROOT = os.path.dirname(HERE)
 sys.path.insert(0, ROOT)
 sys.path.insert(0, HERE)
 
+# the library reads its developer knobs (ORT_EXCHANGE, ORT_KERNEL, ...) once per uploaded scene; the tests flip them between
+# two renders of one cached scene, so they ask for the environment to be read at every render
+os.environ.setdefault("ORT_KNOBS_LIVE", "1")
+
 GOLDEN = os.path.join(HERE, "golden")
 DATA = os.path.join(ROOT, "data")
 

@@ -164,3 +164,16 @@ def test_oracle_on_the_determinant_threshold_scene(api, oracle, manifest, tmp_pa
         img, st = osc.render(W, H, c["spp"], c["seed"], c["policy"], chunk=c["chunk"], rect=(x0, y0, x1, y1), threads=8)
         assert_bits_equal(img[y0:y1, x0:x1], z[c["key"]], c["key"])
         assert st["shapes_tested"] == c["reference"]["shapes_tested"]
+
+
+def test_oracle_equals_the_reference_at_baseline_scale(api, oracle, manifest):
+    """the oracle against the reference's own pixels at BASELINE parameters (1920x1080, 1024 spp, 64-sample jobs): a 16x8
+    corner of each fixture window (tests/golden/baseline_windows.npz; the GPU tests compare the whole 128x72 window)"""
+    z = np.load(os.path.join(GOLDEN, "baseline_windows.npz"))
+    for name in ("c3_bunny_room", "c4_dwarf_room", "c2_analytic"):
+        meta = manifest["glibc_distance_baseline"][name]
+        x0, y0, x1, y1 = meta["window"]
+        scene = api.Scene.load_scn(os.path.join(ROOT, "data", name + ".scn")).commit()
+        rect = (x0, y0, x0 + 16, y0 + 8)
+        img, _ = oracle.OracleScene(scene.flatten(1920, 1080)).render(1920, 1080, 1024, meta["seed"], "chunk", chunk=64, rect=rect, threads=8)
+        assert_bits_equal(img[rect[1]:rect[3], rect[0]:rect[2]], z[name + "__det"][:8, :16], name)

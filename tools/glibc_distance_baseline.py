@@ -4,7 +4,9 @@ as-shipped reference (reference + glibc libm) AT BASELINE SCALE -- a 128x72 wind
 1024 spp in 64-sample jobs (CHUNK policy), same seeds, for the C2 / C3 / C4 scenes.  A libm result that differs in its
 last bit can flip a comparison somewhere along a path; everything after it in that 64-sample job then decorrelates, which
 moves the pixel by O(1/16) of one job's mean.  Writes per-pixel L2 statistics into tests/golden/manifest.json
-("glibc_distance_baseline"); tests/test_oracle_golden.py asserts the stated bounds.
+("glibc_distance_baseline"); tests/test_oracle_golden.py asserts the stated bounds.  Both builds' windows are kept as
+fixtures (tests/golden/baseline_windows.npz: <scene>__det, <scene>__glibc) so that the GPU tests can hold the HIP image
+against the reference's own pixels at BASELINE parameters: bit-equal to __det, within the stated bound of __glibc.
 usage: python3 tools/glibc_distance_baseline.py [workers=8]"""
 import json, os, subprocess, sys, tempfile
 from multiprocessing import Pool
@@ -36,11 +38,13 @@ if __name__ == "__main__":
     with Pool(workers) as pool:
         res = pool.map(run, jobs, chunksize=1)
     report = {}
+    windows = {}
     for scene in WIN:
         imgs = {}
         for b in ("ref_det", "ref_glibc"):
             imgs[b] = np.concatenate([r[3] for r in sorted((r for r in res if r[0] == b and r[1] == scene), key=lambda r: r[2])], axis=0)
         a, g = imgs["ref_det"], imgs["ref_glibc"]
+        windows[scene + "__det"], windows[scene + "__glibc"] = a, g
         l2 = np.sqrt(((a.astype(np.float64) - g.astype(np.float64)) ** 2).sum(axis=2)).ravel()
         hist_edges = [0.0, 1e-7, 1e-6, 1e-5, 1e-4, 1e-3, 1e-2, 1e-1, 1e9]
         hist = np.histogram(l2, bins=hist_edges)[0].tolist()
@@ -53,6 +57,7 @@ if __name__ == "__main__":
             "mean_value": float(a.mean()),
         }
         print(scene, json.dumps(report[scene]))
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "baseline_windows.npz"), **windows)
     mpath = os.path.join(ROOT, "tests", "golden", "manifest.json")
     m = json.load(open(mpath))
     m["glibc_distance_baseline"] = report

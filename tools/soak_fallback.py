@@ -2,6 +2,7 @@
 forced re-cast rate of 1/16 .. 1/256 of the rays must equal the normal render bit for bit.
 usage: python3 tools/soak_fallback.py"""
 import os, sys
+os.environ.setdefault("ORT_KNOBS_LIVE", "1")  # this script flips knobs between renders of one uploaded scene
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
