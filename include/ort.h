@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define ORT_ABI_VERSION 2
+#define ORT_ABI_VERSION 3
 
 enum {
     ORT_OK = 0,
@@ -107,6 +107,9 @@ typedef struct {
     uint64_t ref_bytes;
     /* analytic shapes kept out of the tree and tested outright by every ray (0: all shapes are in the tree) */
     uint32_t prologue_prims;
+    /* the 4-wide form of the same tree (128-byte nodes, up to four children each), which renders of trees that do not
+       fit the L2 traverse instead: half the dependent node fetches per ray */
+    uint32_t wide_node_count, wide_max_depth;
 } ort_tree_info;
 
 /* work counters of one render call (device counters).  All zero unless

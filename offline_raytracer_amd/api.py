@@ -72,7 +72,8 @@ class TreeInfo(C.Structure):
     _fields_ = [("node_count", C.c_uint32), ("leaf_count", C.c_uint32), ("max_leaf_prims", C.c_uint32),
                 ("max_depth", C.c_uint32), ("node_bytes", C.c_uint64), ("prim_bytes", C.c_uint64),
                 ("sah_cost", C.c_float), ("ref_node_count", C.c_uint32), ("ref_nonempty_leaves", C.c_uint32),
-                ("ref_max_leaf_records", C.c_uint32), ("ref_bytes", C.c_uint64), ("prologue_prims", C.c_uint32)]
+                ("ref_max_leaf_records", C.c_uint32), ("ref_bytes", C.c_uint64), ("prologue_prims", C.c_uint32),
+                ("wide_node_count", C.c_uint32), ("wide_max_depth", C.c_uint32)]
 
 
 class Stats(C.Structure):

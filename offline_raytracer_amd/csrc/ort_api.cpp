@@ -280,6 +280,8 @@ static int ort_scene_get_tree_info_impl(const ort_scene *s, ort_tree_info *out) 
     out->ref_bytes = r.nodes.size() * sizeof(ort::DevRefNode) + r.recs.size() * 4 + r.chain_boxes.size() * 16 +
                      (r.tri_chain.size() + r.sphere_chain.size() + r.box_chain.size() + r.cyl_chain.size()) * 8;
     out->prologue_prims = t.pro_boxes + t.pro_spheres + t.pro_cyls;
+    out->wide_node_count = (uint32_t)t.nodes4.size();
+    out->wide_max_depth = t.max_depth4;
     return ORT_OK;
 }
 

@@ -88,7 +88,7 @@ struct PrimInfo { uint32_t chain, mat; };
 struct SceneView {
     const float4 *tab_src;    /* kTabF4 float4, the image of the LDS tables */
     uint32_t tab_flags;
-    const float4 *nodes;      /* 4 per node */
+    const float4 *nodes;      /* 4 per node (DevNode), or -- WIDE kernel variants -- 8 per node (DevNode4) */
     const float4 *tris;       /* 3 per triangle: v0 e1 e2 n (12 floats) */
     const float4 *spheres;    /* 1 per sphere: c.xyz r */
     const float4 *boxes;      /* 2 per box */
@@ -154,24 +154,27 @@ struct RenderView {
     uint32_t park_min;   /* stragglers are parked only when there are at least this many of them (fewer: they idle through one shading pass, cheaper than an exchange step) */
     uint32_t inflight_cap; /* a lane without a path starts a new job only while the wave holds fewer parked paths than this
                               (every parked path is a job in progress: the more a wave holds, the longer its tail) */
-    /* expensive-blocks-first issue of the LAST chunk (CHUNK policy, lpt_order below): u32 words in HBM,
-       [kLptHdr header][cost per local block][finished chunk-0 jobs per local block][kLptBuckets lists of my_blocks] */
+    /* expensive-blocks-first issue of the last lpt_chunks chunks (CHUNK policy, lpt_order below): u32 words in HBM,
+       [kLptHdr header][per local block: finished chunk-0 jobs << 24 | their bounces][kLptBuckets lists of my_blocks] */
     uint32_t *lpt;
+    uint32_t lpt_chunks;
 };
 
-/* ---- the tail of a launch, and the order of the last chunk -----------------------------------------------------
+/* ---- the tail of a launch, and the order of its last jobs --------------------------------------------------------
  * A job is a serial stream of `chunk` samples that only one lane can advance, so a launch ends one job length after
  * its job counter runs dry: the lanes that drew an expensive job last (a bunny pixel costs several wall pixels) finish
- * it alone.  Measured (profiles/r03_scaling_proxy.json): 13 ms on the 61 ms an 8-way shard of the headline frame needs,
- * proportional to the job length.  The job space is [chunk][block][pixel]; every chunk of a pixel costs about the same,
- * so chunk 0 -- finished long before the last chunk is issued -- tells what each 8x8 block costs (bounces counted per
- * job in LDS, summed per block), and the last chunk's blocks are then issued most expensive first (longest processing
- * time first): the jobs drawn last are the cheapest ones.  Which lane renders which job, and when, cannot change a bit
- * of the image (seeds belong to jobs); the permutation is a bijection whatever the costs say, because every block is
- * entered into exactly one bucket list exactly once (by the lane that finishes its 64th chunk-0 job).
+ * it alone.  Measured (profiles/r03_scaling_proxy.json): 12-19 ms on the 57 ms an 8-way shard of the headline frame
+ * needs, proportional to the job length.  The job space is [chunk][block][pixel]; every chunk of a pixel costs about the
+ * same, so chunk 0 -- finished long before the end of the launch -- tells what each 8x8 block costs (bounces counted per
+ * job in LDS, summed per block), and the LAST lpt_chunks chunks (about four jobs per lane: on an 8-way shard one chunk is
+ * one job per lane, and a single sorted round would still end with its most expensive job) are issued as ONE sequence
+ * [block, most expensive first][chunk][pixel]: longest processing time first, the jobs drawn last are the cheapest.
+ * Which lane renders which job, and when, cannot change a bit of the image (seeds belong to jobs); the permutation is a
+ * bijection whatever the costs say, because every block is entered into exactly one bucket list exactly once (by the
+ * lane that finishes its 64th chunk-0 job).
  * Header words: */
 constexpr uint32_t kLptBuckets = 64;
-enum : uint32_t { LPT_BLOCKS_DONE = 0, LPT_READY = 1, LPT_MODE = 2, LPT_COUNT = 8, LPT_START = 8 + kLptBuckets, kLptHdr = 8 + 2 * kLptBuckets + 8 };
+enum : uint32_t { LPT_BLOCKS_DONE = 0, LPT_READY = 1, LPT_MODE = 2, LPT_COUNT = 32, LPT_START = 32 + kLptBuckets, kLptHdr = 32 + 2 * kLptBuckets };
 enum : uint32_t { LPT_UNDECIDED = 0, LPT_SORTED = 1, LPT_NATURAL = 2 };
 
 /* What the kernels receive by value: the handful of render parameters every ray reads; everything else stays in the
@@ -213,7 +216,8 @@ struct Knobs {
     int lds_tables = -1;       /* ORT_LDS_TABLES */
     int exchange = -1;         /* ORT_EXCHANGE */
     int long_min = -1, long_refill = -1, inflight_cap = -1, park_min = -1; /* ORT_LONG_MIN, ORT_LONG_REFILL, ORT_INFLIGHT_CAP, ORT_PARK_MIN */
-    int lpt = -1;              /* ORT_LPT: expensive-blocks-first issue of the last chunk */
+    int lpt = -1;              /* ORT_LPT: expensive-blocks-first issue of the last chunks: 0 off, n > 0 = that many chunks (default: ~4 jobs per lane) */
+    int wide = -1;             /* ORT_WIDE: 4-wide tree (default: for trees that leave the L2) */
     int blocks_per_cu = -1;    /* ORT_BLOCKS_PER_CU (takes effect at upload) */
 };
 static int env_int(const char *name, int unset = -1) {
@@ -238,6 +242,7 @@ static Knobs read_knobs() {
     k.inflight_cap = env_int("ORT_INFLIGHT_CAP");
     k.park_min = env_int("ORT_PARK_MIN");
     k.lpt = env_int("ORT_LPT");
+    k.wide = env_int("ORT_WIDE");
     k.blocks_per_cu = env_int("ORT_BLOCKS_PER_CU");
     return k;
 }
@@ -246,6 +251,7 @@ struct DeviceScene {
     int device = -1;
     Knobs knobs;
     void *nodes = nullptr, *tris = nullptr, *spheres = nullptr, *boxes = nullptr, *cyls = nullptr, *materials = nullptr;
+    void *nodes4 = nullptr; /* the 4-wide form of the tree (uploaded when it exists and its depth fits the traversal stacks) */
     void *prim_info = nullptr;
     uint32_t info_box = 0, info_cyl = 0, info_sphere = 0;
     void *light_is_sphere = nullptr;
@@ -934,13 +940,14 @@ ORT_D V3 focal_point(const RenderHot &rv, uint32_t pxy, V3 cam_p, V3 cam_x, V3 c
 ORT_D uint32_t lpt_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 ORT_D void lpt_store(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 /* a chunk-0 job of local block lb has ended (or was skipped: pixel outside the rect) with `bounces` rays cast beyond
-   its primaries.  The lane that ends the block's 64th job files the block under its cost; the lane that files the last
-   block publishes the lists. */
+   its primaries.  ONE atomic per job: the block's word counts jobs in its top byte and bounces below.  The lane that
+   ends the block's 64th job files the block under its cost; the lane that files the last block publishes the lists. */
 ORT_D void lpt_job_done(uint32_t *lpt, uint32_t my_blocks, uint32_t per_bucket, uint32_t lb, uint32_t bounces) {
-    uint32_t *cost = lpt + kLptHdr, *done = cost + my_blocks, *lists = done + my_blocks;
-    if (bounces) atomicAdd(cost + lb, bounces);
-    if (atomicAdd(done + lb, 1u) != 63u) return;
-    uint32_t b = lpt_load(cost + lb) / per_bucket;
+    uint32_t *acc = lpt + kLptHdr, *lists = acc + my_blocks;
+    bounces = bounces < 0x3ffffu ? bounces : 0x3ffffu; /* 64 jobs stay below 2^24 */
+    const uint32_t old = atomicAdd(acc + lb, (1u << 24) | bounces);
+    if ((old >> 24) != 63u) return;
+    uint32_t b = ((old & 0x00ffffffu) + bounces) / per_bucket;
     b = b < kLptBuckets ? b : kLptBuckets - 1u;
     const uint32_t slot = atomicAdd(lpt + LPT_COUNT + b, 1u);
     lpt_store(lists + (size_t)b * my_blocks + slot, lb);
@@ -954,8 +961,10 @@ ORT_D void lpt_job_done(uint32_t *lpt, uint32_t my_blocks, uint32_t per_bucket, 
     __threadfence();
     lpt_store(lpt + LPT_READY, 1u);
 }
-/* the i-th block of the last chunk: by descending cost when the lists were complete before the first job of the last
-   chunk was decoded (decided once, by whoever decodes first: every lane must use the same order), else in natural order */
+/* the i-th block of the sorted part of the job space: by descending cost when the lists were complete before its first
+   job was decoded (decided once, by whoever decodes first: every lane must use the same order), else in natural order.
+   Once published the lists never change: after the acquire fence they are read with ordinary (cached) loads, the
+   bucket by bisection over the 64 start offsets (START falls from bucket 0 to bucket 63, 0 at the most expensive). */
 ORT_D uint32_t lpt_order(uint32_t *lpt, uint32_t my_blocks, uint32_t i) {
     uint32_t mode = lpt_load(lpt + LPT_MODE);
     if (mode == LPT_UNDECIDED) {
@@ -965,12 +974,13 @@ ORT_D uint32_t lpt_order(uint32_t *lpt, uint32_t my_blocks, uint32_t i) {
     }
     if (mode != LPT_SORTED) return i;
     __threadfence();
-    uint32_t lb = i;
-    for (uint32_t k = 0; k < kLptBuckets; ++k) {
-        const uint32_t first = lpt_load(lpt + LPT_START + k), n = lpt_load(lpt + LPT_COUNT + k);
-        if (i >= first && i < first + n) { lb = lpt_load(lpt + kLptHdr + 2u * my_blocks + (size_t)k * my_blocks + (i - first)); break; }
+    const uint32_t *start = lpt + LPT_START;
+    uint32_t lo = 0u, hi = kLptBuckets - 1u; /* the bucket k with start[k] <= i that is smallest (buckets of equal start are empty but for the last) */
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (start[mid] <= i) hi = mid; else lo = mid + 1u;
     }
-    return lb;
+    return lpt[kLptHdr + my_blocks + (size_t)lo * my_blocks + (i - start[lo])];
 }
 #endif
 
@@ -1109,12 +1119,23 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderHot &rv, const float4 *t
                     uint32_t k = (uint32_t)(j / per_chunk);
                     uint32_t rem = (uint32_t)(j % per_chunk);
                     uint32_t lb = rem >> 6; /* local block */
+                    uint32_t pin = rem & 63u;
 #ifndef ORT_HOST_SIM
                     uint32_t *lpt = (IMPLICIT && rv.mode == JOBS_CHUNK && focal_cache) ? rv.c->lpt : nullptr;
-                    if (lpt && k + 1u == rv.c->nchunks) lb = lpt_order(lpt, rv.c->my_blocks, lb);
+                    if (lpt) {
+                        /* the last lpt_chunks chunks form one sequence [block by descending cost][chunk][pixel] */
+                        const uint32_t nsort = rv.c->lpt_chunks, k0 = rv.c->nchunks - nsort;
+                        if (k >= k0) {
+                            const unsigned long long i = j - (unsigned long long)k0 * per_chunk;
+                            const uint32_t per_block = nsort * 64u;
+                            const uint32_t within = (uint32_t)(i % per_block);
+                            lb = lpt_order(lpt, rv.c->my_blocks, (uint32_t)(i / per_block));
+                            k = k0 + (within >> 6);
+                            pin = within & 63u;
+                        }
+                    }
 #endif
                     uint32_t blk = rv.c->shard_index + lb * rv.c->shard_count;
-                    uint32_t pin = rem & 63u;
                     int x = (int)((rv.c->block_x0 + blk % rv.c->blocks_w) * 8u + (pin & 7u));
                     int y = (int)((rv.c->block_y0 + blk / rv.c->blocks_w) * 8u + (pin >> 3));
                     if (x < rv.c->x0 || x >= rv.c->x1 || y < rv.c->y0 || y >= rv.c->y1) {
@@ -1266,6 +1287,63 @@ ORT_D void visit_node(float4 a, float4 b, float4 cc, float4 d, V3 org, V3 inv_d,
     }
 }
 
+/* One interior node of the 4-wide tree (DevNode4: lo.x, lo.y, lo.z, hi.x, hi.y, hi.z of four children, four child words)
+   against the ray: the same conservative slab test as visit_node per child, then the children that are hit are visited
+   nearest first -- the nearest becomes the current node, the others are stacked farthest first.  Half the dependent
+   fetches of the binary tree on the way down. */
+template <bool COUNTERS, int LDS_ENTRIES, int BLOCK>
+ORT_D void visit_node4(float4 lx, float4 ly, float4 lz, float4 hx, float4 hy, float4 hz, float4 cw, V3 org, V3 inv_d, float best_t, uint32_t &cur, int &sp,
+                       uint32_t *lds_stack, uint32_t *spill, int tid, Counters &c) {
+    if (COUNTERS) c.nodes += 4;
+    float key0, key1, key2, key3;
+    uint32_t w0, w1, w2, w3;
+#define ORT_SLAB4(K, W, LX, LY, LZ, HX, HY, HZ, CW)                                                                        \
+    {                                                                                                                      \
+        const float t0x = ((LX) - org.x) * inv_d.x, t1x = ((HX) - org.x) * inv_d.x;                                        \
+        const float t0y = ((LY) - org.y) * inv_d.y, t1y = ((HY) - org.y) * inv_d.y;                                        \
+        const float t0z = ((LZ) - org.z) * inv_d.z, t1z = ((HZ) - org.z) * inv_d.z;                                        \
+        const float n_ = fmaxf(fmaxf(fminf(t0x, t1x), fminf(t0y, t1y)), fminf(t0z, t1z));                                  \
+        const float f_ = fminf(fminf(fmaxf(t0x, t1x), fmaxf(t0y, t1y)), fmaxf(t0z, t1z));                                  \
+        const uint32_t cw_ = om_f32_bits(CW);                                                                              \
+        const bool hit_ = (f_ * 1.0000004f >= n_) && (f_ >= 0.0f) && ((n_ * kCullSlack < best_t) || (cw_ & SPHERE_BELOW_BIT)) && (cw_ != EMPTY_CHILD); \
+        K = hit_ ? fminf(n_, 3.402823466e+38f) : __builtin_inff(); /* a hit sorts strictly before every miss */             \
+        W = hit_ ? cw_ : EMPTY_CHILD;                                                                                      \
+    }
+    ORT_SLAB4(key0, w0, lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, cw.x)
+    ORT_SLAB4(key1, w1, lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, cw.y)
+    ORT_SLAB4(key2, w2, lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, cw.z)
+    ORT_SLAB4(key3, w3, lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, cw.w)
+#undef ORT_SLAB4
+    /* ascending by entry distance: five compare-exchanges */
+#define ORT_CX(KA, WA, KB, WB)                                                                                             \
+    {                                                                                                                      \
+        const bool sw_ = KB < KA;                                                                                          \
+        const float ka_ = sw_ ? KB : KA, kb_ = sw_ ? KA : KB;                                                              \
+        const uint32_t wa_ = sw_ ? WB : WA, wb_ = sw_ ? WA : WB;                                                           \
+        KA = ka_; KB = kb_; WA = wa_; WB = wb_;                                                                            \
+    }
+    ORT_CX(key0, w0, key1, w1)
+    ORT_CX(key2, w2, key3, w3)
+    ORT_CX(key0, w0, key2, w2)
+    ORT_CX(key1, w1, key3, w3)
+    ORT_CX(key1, w1, key2, w2)
+#undef ORT_CX
+    if (w0 == EMPTY_CHILD) { /* nothing hit: pop */
+        if (sp == 0) {
+            cur = kTraversalDone;
+        } else {
+            sp--;
+            if (sp < LDS_ENTRIES) cur = lds_stack[sp * BLOCK + tid];
+            else cur = ((volatile uint32_t *)spill)[sp - LDS_ENTRIES];
+        }
+        return;
+    }
+    cur = w0;
+    if (w3 != EMPTY_CHILD) { if (sp < LDS_ENTRIES) lds_stack[sp * BLOCK + tid] = w3; else spill[sp - LDS_ENTRIES] = w3; sp++; }
+    if (w2 != EMPTY_CHILD) { if (sp < LDS_ENTRIES) lds_stack[sp * BLOCK + tid] = w2; else spill[sp - LDS_ENTRIES] = w2; sp++; }
+    if (w1 != EMPTY_CHILD) { if (sp < LDS_ENTRIES) lds_stack[sp * BLOCK + tid] = w1; else spill[sp - LDS_ENTRIES] = w1; sp++; }
+}
+
 /* raycast_top_most_node (ray.cpp:1165-1176): start at the root.  The lanes that start a ray now are converged: they
    test the analytic prologue together and visit the root node together, its record read from the LDS tables, before
    they join the traversal loop (whose other lanes are at arbitrary depths) */
@@ -1292,7 +1370,7 @@ ORT_D void begin_ray(const SceneView &sv, const float4 *tab, const PathState &P,
  * conservative; fminf/fmaxf drop the NaN of 0 * inf, i.e. that axis is ignored.
  * Returns when this lane's ray is finished, or -- refill_below > 0 -- as soon as fewer than
  * refill_below lanes of the wave are still traversing (the caller resumes later: all state is in T/h). */
-template <bool COUNTERS, int LDS_ENTRIES, int BLOCK, bool TREELET = false, bool ANNOUNCE = false>
+template <bool COUNTERS, int LDS_ENTRIES, int BLOCK, bool TREELET = false, bool ANNOUNCE = false, bool WIDE = false>
 ORT_D bool traverse(const SceneView &sv, V3 org, V3 dir, Trav &T, HitState &h, uint32_t *lds_stack, uint32_t *spill, int tid,
                     int refill_below, int descend_below, Counters &c, Prof &pr, uint32_t excl = kNoPrim, const float4 *tab = nullptr) {
     bool tracing = true;
@@ -1313,6 +1391,11 @@ ORT_D bool traverse(const SceneView &sv, V3 org, V3 dir, Trav &T, HitState &h, u
 #endif
             ORT_UTIL(sv, 0, true);
             const uint32_t ni = cur & NODE_INDEX_MASK;
+            if (WIDE) { /* sv.nodes holds the 4-wide form (DevNode4, 8 float4 each): seven 16-byte loads in flight together */
+                const float4 *np = sv.nodes + 8u * ni;
+                const float4 lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5], cw = np[6];
+                visit_node4<COUNTERS, LDS_ENTRIES, BLOCK>(lx, ly, lz, hx, hy, hz, cw, org, inv_d, h.best_t, cur, sp, lds_stack, spill, tid, c);
+            } else {
             float4 na, nb, nc, nd;
             if (TREELET && ni < kTreeletNodes) { /* the top of the tree: LDS */
                 const float4 *np = tab + kTabTreelet + 4u * ni;
@@ -1322,6 +1405,7 @@ ORT_D bool traverse(const SceneView &sv, V3 org, V3 dir, Trav &T, HitState &h, u
                 na = np[0]; nb = np[1]; nc = np[2]; nd = np[3];
             }
             visit_node<COUNTERS, LDS_ENTRIES, BLOCK>(na, nb, nc, nd, org, inv_d, h.best_t, cur, sp, lds_stack, spill, tid, c);
+            }
 #if ORT_TRAV_WHILEWHILE
             /* the stragglers of the descend loop would keep the rest of the wave waiting: break out
                and come back for them (their cur / sp carry over) */
@@ -1379,7 +1463,7 @@ ORT_D bool traverse(const SceneView &sv, V3 org, V3 dir, Trav &T, HitState &h, u
    The extra traversals run here, to completion, for the lanes that need them (1e-5 of the rays of the
    reference's scenes, 1e-2 with slanted cylinders) while the rest of the wave waits: the shape to ignore is
    a local of this rare branch, not a register carried through every ray's traversal. */
-template <bool COUNTERS, bool TABS, int LDS_ENTRIES, int BLOCK, bool ANNOUNCED = false>
+template <bool COUNTERS, bool TABS, int LDS_ENTRIES, int BLOCK, bool ANNOUNCED = false, bool WIDE = false>
 ORT_D void resolve_hit(const SceneView &sv, const float4 *tab, V3 org, V3 dir, V3 inv_d, uint32_t lane_id, HitState &h, Counters &c, Prof &pr,
                        uint32_t *lds_stack, uint32_t *spill, int tid) {
     /* the winner's chain word and material index: announced by the traversal (in the lane's stack entries 0 and 1),
@@ -1416,7 +1500,7 @@ ORT_D void resolve_hit(const SceneView &sv, const float4 *tab, V3 org, V3 dir, V
                 /* CH_UNKNOWN: only hits at or before the leaf box's entry matter (the hit tests' "<" must accept t == gap) */
                 reset_hit(h, verdict == CH_REJECT ? 3.402823466e+38f : om_bits_f32(om_f32_bits(gap) + 1u));
                 prologue_tests<COUNTERS, TABS>(sv, tab, org, dir, inv_d, h, c, w_prim);
-                (void)traverse<COUNTERS, LDS_ENTRIES - 4, BLOCK>(sv, org, dir, t2, h, lds_stack, spill, tid, 0, 0, c, pr, w_prim);
+                (void)traverse<COUNTERS, LDS_ENTRIES - 4, BLOCK, false, false, WIDE>(sv, org, dir, t2, h, lds_stack, spill, tid, 0, 0, c, pr, w_prim);
                 if (verdict == CH_UNKNOWN) {
                     if (h.hit_prim != kNoPrim || h.phantom_t <= gap) {
                         recast = true; /* something is there: order decides */
@@ -1453,7 +1537,7 @@ ORT_D void flush_counters(const RenderHot &rv, const Counters &c, bool all) {
 }
 
 /* persistent mode: one lane runs jobs until the job space is empty */
-template <bool COUNTERS, bool DIFFUSE = false, bool TABS = false, bool IMPLICIT = false>
+template <bool COUNTERS, bool DIFFUSE = false, bool TABS = false, bool IMPLICIT = false, bool WIDE = false>
 ORT_D void pt_lane(const SceneView &sv, const RenderHot &rv, const float4 *tab, uint32_t *lds_stack, float *lds_focal, const int tid,
                    const uint32_t lane_id, bool prof_on = false) {
     uint32_t spill[kSpillStack];
@@ -1473,7 +1557,7 @@ ORT_D void pt_lane(const SceneView &sv, const RenderHot &rv, const float4 *tab, 
             ORT_UTIL(sv, 3, true);
             ORT_UTIL(sv, 4, P.ps == PS_HIT);
             ORT_PHASE(pr, sv, 7, true);
-            if (P.ps == PS_HIT) resolve_hit<COUNTERS, TABS, kLdsStack, kBlock, true>(sv, tab, P.org, P.dir, T.inv_d, lane_id, h, c, pr, lds_stack, spill, tid);
+            if (P.ps == PS_HIT) resolve_hit<COUNTERS, TABS, kLdsStack, kBlock, true, WIDE>(sv, tab, P.org, P.dir, T.inv_d, lane_id, h, c, pr, lds_stack, spill, tid);
             ORT_PHASE(pr, sv, 0, P.ps == PS_HIT);
             tracing = produce_ray<COUNTERS, DIFFUSE, TABS, IMPLICIT>(sv, rv, tab, P, h, c, pr, lds_focal + tid, kBlock, spp_u);
             if (tracing) {
@@ -1482,7 +1566,7 @@ ORT_D void pt_lane(const SceneView &sv, const RenderHot &rv, const float4 *tab, 
             }
         }
         if (ORT_BALLOT(P.ps != PS_DONE) == 0ull) break;
-        if (tracing) tracing = traverse<COUNTERS, kLdsStack, kBlock, TABS, true>(sv, P.org, P.dir, T, h, lds_stack, spill, tid, rv.refill_below, rv.descend_below, c, pr, kNoPrim, tab);
+        if (tracing) tracing = traverse<COUNTERS, kLdsStack, kBlock, TABS && !WIDE, true, WIDE>(sv, P.org, P.dir, T, h, lds_stack, spill, tid, rv.refill_below, rv.descend_below, c, pr, kNoPrim, tab);
     }
     flush_counters(rv, c, COUNTERS);
 }
@@ -1775,7 +1859,7 @@ __device__ __forceinline__ void fill_tab(const SceneView &sv, float4 *lds_tab) {
     __syncthreads();
 }
 
-template <bool COUNTERS, bool DIFFUSE, bool TABS, bool IMPLICIT = false>
+template <bool COUNTERS, bool DIFFUSE, bool TABS, bool IMPLICIT = false, bool WIDE = false>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(ORT_WAVES_PER_EU, ORT_WAVES_PER_EU)))
 pt_persistent(SceneView sv, RenderHot rv) {
     __shared__ uint32_t lds_stack[kLdsStack * kBlock];
@@ -1788,7 +1872,7 @@ pt_persistent(SceneView sv, RenderHot rv) {
         if (threadIdx.x < 4) g_lds_prof[96 + threadIdx.x] = __builtin_amdgcn_s_memtime();
         __syncthreads();
     }
-    pt_lane<COUNTERS, DIFFUSE, TABS, IMPLICIT>(sv, rv, lds_tab, lds_stack, lds_focal, (int)threadIdx.x, blockIdx.x * (uint32_t)kBlock + threadIdx.x, prof);
+    pt_lane<COUNTERS, DIFFUSE, TABS, IMPLICIT, WIDE>(sv, rv, lds_tab, lds_stack, lds_focal, (int)threadIdx.x, blockIdx.x * (uint32_t)kBlock + threadIdx.x, prof);
     if (prof) {
         __syncthreads();
         if (threadIdx.x < 96 && g_lds_prof[threadIdx.x]) atomicAdd(sv.util + threadIdx.x, g_lds_prof[threadIdx.x]);
@@ -1955,7 +2039,7 @@ void device_release(Scene *scene) {
     DeviceScene *d = scene->dev;
     if (!d) return;
     (void)hipSetDevice(d->device);
-    void *ptrs[] = {d->nodes, d->tris, d->spheres, d->boxes, d->cyls, d->prim_info,
+    void *ptrs[] = {d->nodes, d->nodes4, d->tris, d->spheres, d->boxes, d->cyls, d->prim_info,
                     d->materials, d->light_is_sphere, d->tab, d->cold, d->rv_dev, d->ref_nodes, d->ref_recs, d->chain_boxes, d->tri_order, d->sphere_order, d->box_order, d->cyl_order, d->bfs_pool, d->bfs_locks, d->ctrl, d->partial, d->staging, d->jobs, d->states};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -1983,6 +2067,9 @@ int device_upload(Scene *scene, int device, std::string *err) {
     scene->dev = d;
     const Tree &t = scene->tree;
     if ((rc = upload_vec(t.nodes, &d->nodes, err))) return rc;
+    /* a traversal of the wide tree stacks at most three entries per level; the smallest stack is resolve_hit's re-traversal */
+    if (!t.nodes4.empty() && 3u * t.max_depth4 <= (uint32_t)(kLdsStack - 4 + kSpillStack))
+        if ((rc = upload_vec(t.nodes4, &d->nodes4, err))) return rc;
     if ((rc = upload_vec(t.tris, &d->tris, err))) return rc;
     if ((rc = upload_vec(t.spheres, &d->spheres, err))) return rc;
     if ((rc = upload_vec(t.boxes, &d->boxes, err))) return rc;
@@ -2339,10 +2426,17 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
        whose jobs measure the blocks, is long finished when the last chunk is issued (if it is not, the kernel notices and
        keeps the natural order).  ORT_LPT=0 switches it off (A/B runs; same image either way). */
     if (!wavefront && rv.mode == JOBS_CHUNK && rv.nchunks >= 4u && rv.my_blocks > 0u && kn.lpt != 0) {
-        const size_t words = (size_t)kLptHdr + (size_t)(2u + kLptBuckets) * rv.my_blocks;
+        const size_t words = (size_t)kLptHdr + (size_t)(1u + kLptBuckets) * rv.my_blocks;
         if ((rc = ensure(&d->lpt, &d->lpt_bytes, words * sizeof(uint32_t), err))) return rc;
-        ORT_HIP(hipMemsetAsync(d->lpt, 0, ((size_t)kLptHdr + 2u * (size_t)rv.my_blocks) * sizeof(uint32_t), stream));
+        ORT_HIP(hipMemsetAsync(d->lpt, 0, ((size_t)kLptHdr + (size_t)rv.my_blocks) * sizeof(uint32_t), stream));
         rv.lpt = (uint32_t *)d->lpt;
+        /* as many chunks as give every lane about four sorted jobs, at least one, and never the first two chunks (chunk 0
+           measures; its last jobs must have ended before the first sorted job is decoded) */
+        const unsigned long long lanes = (unsigned long long)d->max_blocks * kBlock, per_chunk = (unsigned long long)rv.my_blocks * 64ull;
+        unsigned long long want = kn.lpt > 0 ? (unsigned long long)kn.lpt : (4ull * lanes + per_chunk - 1ull) / per_chunk;
+        if (want < 1ull) want = 1ull;
+        if (want > rv.nchunks - 2u) want = rv.nchunks - 2u;
+        rv.lpt_chunks = (uint32_t)want;
     }
     /* the RenderView goes to HBM (pageable source: the copy is staged before the call returns); the kernels get the few
        fields every ray reads by value and a pointer to the rest */
@@ -2357,6 +2451,17 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
         if (rc) return rc;
     } else {
 #define ORT_LAUNCH(C, D, T) hipLaunchKernelGGL((pt_persistent<C, D, T>), dim3(grid), dim3(kBlock), 0, stream, sv, hot)
+        /* 4-wide tree (DevNode4): half the dependent node fetches per ray, for trees that leave the L2 (the 1M-triangle
+           scene); the cache-resident scenes make ~1.5 node visits per ray after the prologue and keep the leaner binary
+           variants.  ORT_WIDE=0 / 1 forces it (same image either way). */
+        const bool wide = d->nodes4 && !exch && tabs && (counters || rv.mode != JOBS_EXPLICIT) && !(counters && diffuse && want_util) &&
+                          (kn.wide >= 0 ? kn.wide != 0 : !cache_resident_tree);
+        if (wide) {
+            sv.nodes = (const float4 *)d->nodes4;
+            if (counters) hipLaunchKernelGGL((pt_persistent<true, false, true, false, true>), dim3(grid), dim3(kBlock), 0, stream, sv, hot);
+            else if (diffuse) hipLaunchKernelGGL((pt_persistent<false, true, true, true, true>), dim3(grid), dim3(kBlock), 0, stream, sv, hot);
+            else hipLaunchKernelGGL((pt_persistent<false, false, true, true, true>), dim3(grid), dim3(kBlock), 0, stream, sv, hot);
+        } else
         if (exch) {
             if (counters) hipLaunchKernelGGL((pt_persistent_x<true, true>), dim3(grid), dim3(kBlock), 0, stream, sv, hot); /* diagnostics: probes of the diffuse flavour */
             else if (diffuse) hipLaunchKernelGGL((pt_persistent_x<false, true>), dim3(grid), dim3(kBlock), 0, stream, sv, hot);

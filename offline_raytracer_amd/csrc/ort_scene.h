@@ -52,6 +52,18 @@ constexpr uint32_t kTreeDepthBudget = 60;
 #endif
 constexpr uint32_t kTreeletNodes = ORT_TREELET_NODES; /* the breadth-first top of the fast tree has indices [0, 32): kept in LDS by the kernel */
 
+/* Wide node (128 B): the same tree with every other level folded away -- up to FOUR children per node, their boxes
+ * stored by coordinate (lo.x of the four children in one 16-byte word, ...) and the four child words; child words as in
+ * DevNode, unused slots = EMPTY_CHILD with an inverted box.  A ray then makes half the dependent node fetches on its
+ * way down, which is what bounds deep trees (the 1M-triangle scene: ~10 binary visits per ray; profiles/r02_tuning.md).
+ * Built from the binary tree by ort_tree.cpp (collapse_to_wide); used by the kernel variant for trees that leave the L2. */
+struct DevNode4 {
+    float lox[4], loy[4], loz[4], hix[4], hiy[4], hiz[4];
+    uint32_t child[4];
+    uint32_t pad[4];
+};
+static_assert(sizeof(DevNode4) == 128, "wide node record must be 128 B");
+
 inline uint32_t make_leaf(uint32_t kind, uint32_t first, uint32_t count) {
     return LEAF_BIT | (kind << 28) | ((count - 1u) << 24) | (first & 0x00ffffffu);
 }
@@ -86,6 +98,8 @@ DevMaterial make_dev_material(const ort_material &m); /* ort_tree.cpp */
 
 struct Tree {
     std::vector<DevNode> nodes;
+    std::vector<DevNode4> nodes4; /* the 4-wide form of the same tree (empty if it was not built) */
+    uint32_t max_depth4 = 0;      /* levels of the wide tree: a traversal stacks at most 3 entries per level */
     std::vector<DevTri> tris;
     std::vector<uint32_t> tri_mat;
     std::vector<DevSphere> spheres;

@@ -348,6 +348,86 @@ static void renumber_top_levels(Tree *tree, uint32_t top) {
     tree->nodes.swap(out);
 }
 
+/* The 4-wide form of the finished binary tree: a wide node adopts its binary node's two children and then, while it has
+   fewer than four, replaces the interior child with the largest box by that child's own two children (the usual
+   surface-area-greedy collapse).  Leaves and primitive arrays are shared with the binary tree.  Nodes are emitted
+   breadth-first, so the top of the tree has the lowest indices (the kernel keeps the first kTreeletNodes / 2 in LDS). */
+static void collapse_to_wide(Tree *tree) {
+    tree->nodes4.clear();
+    tree->max_depth4 = 0;
+    const std::vector<DevNode> &bn = tree->nodes;
+    if (bn.empty()) return;
+    struct Cand { uint32_t word; float lo[3], hi[3]; };
+    auto area = [](const Cand &c) {
+        const float dx = c.hi[0] - c.lo[0], dy = c.hi[1] - c.lo[1], dz = c.hi[2] - c.lo[2];
+        return (dx < 0 || dy < 0 || dz < 0) ? 0.0f : dx * dy + dy * dz + dz * dx;
+    };
+    auto children_of = [&bn](uint32_t bi, Cand out[2]) {
+        const DevNode &n = bn[bi];
+        out[0].word = n.child0; memcpy(out[0].lo, n.lo0, 12); memcpy(out[0].hi, n.hi0, 12);
+        out[1].word = n.child1; memcpy(out[1].lo, n.lo1, 12); memcpy(out[1].hi, n.hi1, 12);
+    };
+    struct Todo { uint32_t binary, wide, depth; };
+    std::vector<Todo> queue;
+    tree->nodes4.push_back(DevNode4{});
+    queue.push_back(Todo{0u, 0u, 1u});
+    for (size_t h = 0; h < queue.size(); ++h) {
+        const Todo td = queue[h];
+        tree->max_depth4 = std::max(tree->max_depth4, td.depth);
+        Cand c[4];
+        uint32_t n = 0;
+        {
+            Cand two[2];
+            children_of(td.binary, two);
+            for (int k = 0; k < 2; ++k)
+                if (two[k].word != EMPTY_CHILD) c[n++] = two[k];
+        }
+        while (n < 4) {
+            int pick = -1;
+            float best = -1.0f;
+            for (uint32_t k = 0; k < n; ++k)
+                if (!(c[k].word & LEAF_BIT) && area(c[k]) > best) { best = area(c[k]); pick = (int)k; }
+            if (pick < 0) break;
+            Cand two[2];
+            children_of(c[pick].word & NODE_INDEX_MASK, two);
+            uint32_t live = 0;
+            for (int k = 0; k < 2; ++k)
+                if (two[k].word != EMPTY_CHILD) live++;
+            if (n - 1 + live > 4) break;
+            /* the adopted children take the expanded child's place, in their own order */
+            Cand next[4];
+            uint32_t m = 0;
+            for (uint32_t k = 0; k < n; ++k) {
+                if ((int)k != pick) { next[m++] = c[k]; continue; }
+                for (int j = 0; j < 2; ++j)
+                    if (two[j].word != EMPTY_CHILD) next[m++] = two[j];
+            }
+            n = m;
+            for (uint32_t k = 0; k < n; ++k) c[k] = next[k];
+        }
+        DevNode4 w{};
+        for (uint32_t k = 0; k < 4; ++k) {
+            if (k < n) {
+                w.lox[k] = c[k].lo[0]; w.loy[k] = c[k].lo[1]; w.loz[k] = c[k].lo[2];
+                w.hix[k] = c[k].hi[0]; w.hiy[k] = c[k].hi[1]; w.hiz[k] = c[k].hi[2];
+                if (c[k].word & LEAF_BIT) {
+                    w.child[k] = c[k].word;
+                } else {
+                    const uint32_t wi = (uint32_t)tree->nodes4.size();
+                    tree->nodes4.push_back(DevNode4{});
+                    queue.push_back(Todo{c[k].word & NODE_INDEX_MASK, wi, td.depth + 1u});
+                    w.child[k] = wi | (c[k].word & SPHERE_BELOW_BIT);
+                }
+            } else {
+                w.lox[k] = w.loy[k] = w.loz[k] = FLT_MAX;
+                w.hix[k] = w.hiy[k] = w.hiz[k] = -FLT_MAX;
+                w.child[k] = EMPTY_CHILD;
+            }
+        }
+        tree->nodes4[td.wide] = w;
+    }
+}
+
 int build_tree(Scene *scene, std::string *err) {
     Tree fresh;
     scene->tree = fresh;
@@ -532,6 +612,7 @@ int build_tree(Scene *scene, std::string *err) {
         return ORT_ERR_UNSUPPORTED;
     }
     renumber_top_levels(tree, kTreeletNodes);
+    collapse_to_wide(tree);
     tree->built = true;
     return ORT_OK;
 }

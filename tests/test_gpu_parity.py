@@ -202,6 +202,59 @@ def test_ray_exchange_equals_plain_loop(api, oracle, gpu_scene, monkeypatch, nam
     assert_bits_equal(b, ref, "exchange vs oracle")
 
 
+@pytest.mark.parametrize("name,w,h,spp,chunk", [("c3_bunny_room", 256, 144, 16, 4), ("testscene", 200, 120, 8, 4), ("c2_analytic", 160, 90, 8, 2),
+                                                  ("c5_heightfield_224", 256, 144, 8, 4), ("rand_b", 160, 90, 8, 8)])
+def test_wide_tree_equals_binary_tree(api, oracle, gpu_scene, monkeypatch, name, w, h, spp, chunk):
+    """the 4-wide form of the fast tree (128-byte nodes, visit_node4: what trees that leave the L2 are traversed with) only
+    changes the order in which a ray meets the boxes: same bits as the binary tree and as the oracle, production and
+    counters kernels, also with every 16th ray re-cast exactly"""
+    scene = gpu_scene(name)
+    assert scene.tree_info()["wide_node_count"] > 0
+    monkeypatch.setenv("ORT_WIDE", "0")
+    a, sa = scene.render(w, h, spp, 23, "chunk", chunk=chunk, counters=True)
+    monkeypatch.setenv("ORT_WIDE", "1")
+    b, sb = scene.render(w, h, spp, 23, "chunk", chunk=chunk, counters=True)
+    c, _ = scene.render(w, h, spp, 23, "chunk", chunk=chunk)
+    assert_bits_equal(a, b, "wide vs binary (counters kernels)")
+    assert_bits_equal(a, c, "wide production kernel")
+    assert sa["rays"] == sb["rays"] and sa["paths"] == sb["paths"]
+    if name in ("c3_bunny_room", "c5_heightfield_224", "testscene"):
+        assert sb["node_tests"] != sa["node_tests"]  # it really was another tree
+    monkeypatch.setenv("ORT_DEBUG_FORCE_FALLBACK", "0xf")
+    e, _ = scene.render(w, h, spp, 23, "chunk", chunk=chunk)
+    assert_bits_equal(a, e, "wide tree with forced exact re-casts")
+    monkeypatch.delenv("ORT_DEBUG_FORCE_FALLBACK")
+    ref, _ = oracle.OracleScene(scene.flatten(w, h)).render(w, h, spp, 23, "chunk", chunk=chunk, threads=16)
+    assert_bits_equal(b, ref, "wide tree vs oracle")
+
+
+def test_cost_ordered_issue_of_the_last_chunks(api, gpu_scene, monkeypatch):
+    """CHUNK renders issue their last chunks most-expensive-block first (lpt_order; chunk 0 measures the blocks): same
+    image with it on (default), off, and with 1 / 3 sorted chunks; whole frames, clipped rects and packed shards"""
+    scene = gpu_scene("c3_bunny_room")
+    w, h, spp, chunk, seed = 333, 187, 24, 2, 5  # 12 chunks, ragged edge blocks
+    monkeypatch.setenv("ORT_LPT", "0")
+    a, _ = scene.render(w, h, spp, seed, "chunk", chunk=chunk)
+    for v in (None, "1", "3", "10"):
+        if v is None:
+            monkeypatch.delenv("ORT_LPT")
+        else:
+            monkeypatch.setenv("ORT_LPT", v)
+        b, _ = scene.render(w, h, spp, seed, "chunk", chunk=chunk)
+        assert_bits_equal(a, b, "ORT_LPT=%s" % v)
+        r, _ = scene.render(w, h, spp, seed, "chunk", chunk=chunk, rect=(37, 21, 290, 150))
+        assert_bits_equal(a[21:150, 37:290], r[21:150, 37:290], "clipped rect, ORT_LPT=%s" % v)
+        acc = np.zeros_like(a)
+        for k in range(3):
+            part, _ = scene.render(w, h, spp, seed, "chunk", chunk=chunk, shard=(k, 3))
+            acc += part
+        assert_bits_equal(a, acc, "3-way shard union, ORT_LPT=%s" % v)
+    monkeypatch.setenv("ORT_EXCHANGE", "1")
+    monkeypatch.delenv("ORT_LPT", raising=False)
+    x, _ = scene.render(w, h, spp, seed, "chunk", chunk=chunk)
+    assert_bits_equal(a, x, "sorted issue with the ray exchange")
+
+
 def test_determinism(api, gpu_scene):
     scene = gpu_scene("testscene")
     a, _ = scene.render(128, 72, 8, 1, "chunk", chunk=4)

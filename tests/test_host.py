@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol(api):
     import re
     declared = set(re.findall(r"\b(ort_[a-z0-9_]+)\s*\(", hdr)) - {"ort_unit_eval_device)"}
     assert declared == set(api.EXPORTS)
-    assert L.ort_abi_version() == 2
+    assert L.ort_abi_version() == 3
 
 
 def test_dynamic_symbols_are_c_linkage(api):

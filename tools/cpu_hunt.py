@@ -23,7 +23,7 @@ def one(k):
     ref, _ = oracle_lib.OracleScene(sc.flatten(W, H)).render(W, H, spp, seed, policy, chunk=max(chunk, 1), rr=rr, threads=1)
     out = os.path.join(tempfile.gettempdir(), "hunt_%d.f32" % os.getpid())
     subprocess.run([os.path.join(ROOT, "tools", "host_sim"), scn, os.path.join(ROOT, "data") + "/", str(W), str(H), str(spp), str(seed), policy,
-                    str(chunk), out], capture_output=True, env=dict(os.environ, SIM_RR=repr(rr)))
+                    str(chunk), out], capture_output=True, env=dict(os.environ, SIM_RR=repr(rr), **({"SIM_WIDE": "1"} if (k // 3) % 2 else {})))  # every other triple of cases walks the 4-wide tree
     img = np.fromfile(out, dtype="<f4").reshape(H, W, 3)
     d = int((img.view("<u4") != ref.view("<u4")).any(axis=2).sum())
     return (name, seed, rr, policy, d)

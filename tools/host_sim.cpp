@@ -137,6 +137,12 @@ int main(int argc, char **argv) {
         }
         flush_counters(hot, c, true);
     } else
+    if (getenv("SIM_WIDE")) { /* the 4-wide form of the tree (DevNode4, visit_node4) */
+        if (t.nodes4.empty()) { fprintf(stderr, "no wide tree\n"); return 1; }
+        fprintf(stderr, "wide tree: %zu nodes, depth %u\n", t.nodes4.size(), t.max_depth4);
+        sv.nodes = (const float4 *)t.nodes4.data();
+        pt_lane<true, false, false, false, true>(sv, hot, nullptr, lds.data(), lds_focal.data(), 0, 0);
+    } else
     if (getenv("SIM_DIFFUSE")) pt_lane<true, true>(sv, hot, nullptr, lds.data(), lds_focal.data(), 0, 0); /* caller vouches for Ks = Kt = 0 */
     else pt_lane<true>(sv, hot, nullptr, lds.data(), lds_focal.data(), 0, 0); /* TABS = false: the small tables are read from their arrays */
     if (rv.mode == JOBS_CHUNK)
