@@ -32,7 +32,9 @@ enum {
     ORT_ERR_NO_DEVICE = 4,   /* no HIP device / scene not uploaded */
     ORT_ERR_HIP = 5,         /* a HIP call failed; see ort_last_error() */
     ORT_ERR_UNSUPPORTED = 6, /* e.g. OBJ v/vt faces (parser.cpp:921-923) */
-    ORT_ERR_STATE = 7        /* call order (render before commit/upload) */
+    ORT_ERR_STATE = 7,       /* call order (render before commit/upload) */
+    ORT_ERR_NO_MEMORY = 8,   /* a host allocation failed */
+    ORT_ERR_INTERNAL = 9     /* an exception the C++ side did not expect; see ort_last_error() */
 };
 
 /* thread-local description of the last failure on this thread */

@@ -15,7 +15,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ORT_LIB", os.path.join(PKG_DIR, "lib", "libort.so"))  # ORT_LIB: tuning builds only
 CSRC_DIR = os.path.join(PKG_DIR, "csrc")
 
-OK, ERR_INVALID, ERR_IO, ERR_PARSE, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_STATE = range(8)
+OK, ERR_INVALID, ERR_IO, ERR_PARSE, ERR_NO_DEVICE, ERR_HIP, ERR_UNSUPPORTED, ERR_STATE, ERR_NO_MEMORY, ERR_INTERNAL = range(10)
 POLICY_TILE32, POLICY_WHOLE, POLICY_PIXEL, POLICY_CHUNK = range(4)
 POLICIES = {"tile32": POLICY_TILE32, "whole": POLICY_WHOLE, "pixel": POLICY_PIXEL, "chunk": POLICY_CHUNK}
 RENDER_COUNTERS = 1

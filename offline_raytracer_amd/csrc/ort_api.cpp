@@ -9,6 +9,7 @@
 
 #include <exception>
 #include <new>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -117,11 +118,11 @@ int guarded(F f) {
     try {
         return f();
     } catch (const std::bad_alloc &) {
-        return fail(ORT_ERR_INVALID, "out of memory");
+        return fail(ORT_ERR_NO_MEMORY, "out of memory");
     } catch (const std::exception &e) {
-        return fail(ORT_ERR_INVALID, std::string("internal error: ") + e.what());
+        return fail(ORT_ERR_INTERNAL, std::string("internal error: ") + e.what());
     } catch (...) {
-        return fail(ORT_ERR_INVALID, "internal error");
+        return fail(ORT_ERR_INTERNAL, "internal error");
     }
 }
 
@@ -133,16 +134,13 @@ static int ort_abi_version_impl(void) { return ORT_ABI_VERSION; }
 static int ort_scene_parse_scn_impl(const char *text, size_t size, const char *base_dir, ort_scene **out) {
     if (!text || !out) return fail(ORT_ERR_INVALID, "null argument");
     *out = nullptr;
-    ort_scene *s = new (std::nothrow) ort_scene();
-    if (!s) return fail(ORT_ERR_INVALID, "out of memory");
+    std::unique_ptr<ort_scene> s(new (std::nothrow) ort_scene()); /* owned here until handed out: the parser may throw (bad_alloc on hostile input) */
+    if (!s) return fail(ORT_ERR_NO_MEMORY, "out of memory");
     std::string err;
-    int rc = ort::parse_scn_text(text, size, base_dir, s, &err);
-    if (rc != ORT_OK) {
-        delete s;
-        return fail(rc, err);
-    }
+    int rc = ort::parse_scn_text(text, size, base_dir, s.get(), &err);
+    if (rc != ORT_OK) return fail(rc, err);
     s->reference_csg = true; /* as main() does for every scene it loads (macos_main.mm:322-332) */
-    *out = s;
+    *out = s.release();
     return ORT_OK;
 }
 
@@ -158,7 +156,7 @@ static int ort_scene_create_impl(const ort_scene_desc *d, ort_scene **out) {
     *out = nullptr;
     if (d->material_count == 0) return fail(ORT_ERR_INVALID, "material 0 (the reserved no-hit material) is required");
     ort_scene *s = new (std::nothrow) ort_scene();
-    if (!s) return fail(ORT_ERR_INVALID, "out of memory");
+    if (!s) return fail(ORT_ERR_NO_MEMORY, "out of memory");
     s->materials.assign(d->materials, d->materials + d->material_count);
     if (d->sphere_count) s->spheres.assign(d->spheres, d->spheres + d->sphere_count);
     if (d->box_count) s->boxes.assign(d->boxes, d->boxes + d->box_count);

@@ -24,7 +24,20 @@
 #include <string>
 #include <vector>
 
-#include <rccl/rccl.h> /* types and enum values only; the entry points are looked up with dlsym */
+/* RCCL types and enum values only: the entry points are looked up with dlsym at run time, so a one-GPU build needs
+   neither the library nor -- below -- its header.  Without the header the handful of ABI-stable declarations the
+   gather uses are spelled out here (nccl.h: opaque communicator pointer, 128-byte unique id, result and data-type
+   enums with ncclSuccess = 0 and ncclFloat = 7). */
+#if defined(__has_include) && __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#else
+extern "C" {
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclFloat = 7 } ncclDataType_t;
+}
+#endif
 
 #include "ort_scene.h"
 

@@ -449,6 +449,13 @@ ORT_D float hit_aab_finite(V3 lo, V3 hi, V3 o, V3 inv, V3 &n) {
     }
     return ht;
 }
+/* hit_aab_finite's distance alone (the analytic prologue: the normal is worked out afterwards, for the winner only) */
+ORT_D float hit_aab_t_finite(V3 lo, V3 hi, V3 o, V3 inv) {
+    V3 t0 = had(sub(lo, o), inv), t1 = had(sub(hi, o), inv);
+    float max_of_min = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0.x, t1.x), __builtin_fminf(t0.y, t1.y)), __builtin_fminf(t0.z, t1.z));
+    float min_of_max = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0.x, t1.x), __builtin_fmaxf(t0.y, t1.y)), __builtin_fmaxf(t0.z, t1.z));
+    return (min_of_max >= max_of_min) ? max_of_min : -1.0f;
+}
 /* true when every component is finite (x - x is 0 for a finite x, NaN otherwise) */
 ORT_D bool all_finite6(V3 a, V3 b) {
     return (((a.x - a.x) + (a.y - a.y) + (a.z - a.z)) + ((b.x - b.x) + (b.y - b.y) + (b.z - b.z))) == 0.0f;

@@ -147,7 +147,7 @@ struct RenderView {
     /* ray exchange (pt_lane_x): every wave owns two LIFO stashes in HBM, L for parked paths whose ray is still
        being traversed and R for parked paths whose ray is finished; float4 units */
     float4 *stash;
-    uint32_t stash_wave_f4; /* per wave: L records 7 * capL, L stacks kLdsStack / 4 * capL, R records 7 * capR */
+    uint32_t stash_wave_f4; /* per wave: L records kStashVecs * capL, L stacks kLdsStack / 4 * capL, R records kStashVecs * capR (device_render sizes it) */
     uint32_t capL, capR;
     uint32_t long_min;   /* start a traversal phase on parked rays when tracing lanes + parked rays reach this */
     uint32_t long_refill; /* within such a phase, take more parked rays when fewer lanes than this are tracing */
@@ -746,9 +746,37 @@ ORT_D void prologue_tests(const SceneView &sv, const float4 *tab, V3 org, V3 dir
     const float4 *pb = tab + kTabPro, *ps = pb + 2u * sv.pro_boxes, *pc = ps + sv.pro_spheres;
     /* boxes: when every lane's origin and 1/d are finite (all but a handful of rays), the slab test runs on the
        hardware's min / max (hit_aab_finite: same values); wave-uniform choice, so no lane waits for the other form */
-    if (ORT_BALLOT(!all_finite6(org, inv_d)) == 0ull) {
+#ifndef ORT_PROLOGUE_DEFER
+#define ORT_PROLOGUE_DEFER 1 /* 0: every box test works out its normal (A/B builds; same results) */
+#endif
+    if (!ORT_PROLOGUE_DEFER && ORT_BALLOT(!all_finite6(org, inv_d)) == 0ull) {
         for (uint32_t i = 0; i < sv.pro_boxes; ++i)
             test_prim<COUNTERS, false, true, TABS>(sv, PRIM_BOX, i, org, dir, inv_d, h.best_t, h.hit_n, h.hit_prim, h.phantom_t, h.runner_t, c.tris, c.analytic, excl, pb + 2u * i);
+    } else
+    if (ORT_BALLOT(!all_finite6(org, inv_d)) == 0ull) {
+        /* distances only while the boxes compete (test_prim's rule: accept 1e-6 <= t < best, equal distances by reference
+           test order, the runner-up kept); the entering face's normal is worked out once, below, for the box that won */
+        for (uint32_t i = 0; i < sv.pro_boxes; ++i) {
+            float4 lo, hi;
+            if (TABS) { lo = pb[2u * i]; hi = pb[2u * i + 1u]; } else { lo = sv.boxes[2u * i]; hi = sv.boxes[2u * i + 1u]; }
+            const uint32_t prim = ((uint32_t)PRIM_BOX << 28) | i;
+            if (COUNTERS && prim != excl) c.analytic++;
+            float t = hit_aab_t_finite(mk(lo.x, lo.y, lo.z), mk(hi.x, hi.y, hi.z), org, inv_d);
+            if (ORT_RARE(prim == excl)) t = -1.0f;
+            bool take = (t >= kHitTMin && t < h.best_t);
+            if (ORT_RARE(t == h.best_t && t >= kHitTMin && h.hit_prim != kNoPrim))
+                take = prim_order(sv, PRIM_BOX, i) < prim_order(sv, h.hit_prim >> 28, h.hit_prim & 0x00ffffffu);
+            if (t >= kHitTMin) h.runner_t = fminf(h.runner_t, take ? h.best_t : t);
+            if (take) { h.best_t = t; h.hit_prim = prim; }
+        }
+        if ((h.hit_prim >> 28) == PRIM_BOX && h.hit_prim != kNoPrim) { /* reset_hit precedes every prologue: a box winner here is one of these */
+            const uint32_t i = h.hit_prim & 0x00ffffffu;
+            float4 lo, hi;
+            if (TABS) { lo = pb[2u * i]; hi = pb[2u * i + 1u]; } else { lo = sv.boxes[2u * i]; hi = sv.boxes[2u * i + 1u]; }
+            V3 n = mk(0, 0, 0);
+            (void)hit_aab_finite(mk(lo.x, lo.y, lo.z), mk(hi.x, hi.y, hi.z), org, inv_d, n);
+            h.hit_n = n;
+        }
     } else {
         for (uint32_t i = 0; i < sv.pro_boxes; ++i)
             test_prim<COUNTERS, false, false, TABS>(sv, PRIM_BOX, i, org, dir, inv_d, h.best_t, h.hit_n, h.hit_prim, h.phantom_t, h.runner_t, c.tris, c.analytic, excl, pb + 2u * i);
@@ -963,17 +991,21 @@ ORT_D void lpt_job_done(uint32_t *lpt, uint32_t my_blocks, uint32_t per_bucket, 
 }
 /* the i-th block of the sorted part of the job space: by descending cost when the lists were complete before its first
    job was decoded (decided once, by whoever decodes first: every lane must use the same order), else in natural order.
-   Once published the lists never change: after the acquire fence they are read with ordinary (cached) loads, the
+   Once published the lists never change: they are read with ordinary (cached) loads, the
    bucket by bisection over the 64 start offsets (START falls from bucket 0 to bucket 63, 0 at the most expensive). */
 ORT_D uint32_t lpt_order(uint32_t *lpt, uint32_t my_blocks, uint32_t i) {
-    uint32_t mode = lpt_load(lpt + LPT_MODE);
+    uint32_t mode = lpt[LPT_MODE]; /* an ordinary load: a decision, once seen, is final; a stale "undecided" only leads to the atomics below */
+    if (mode == LPT_UNDECIDED) mode = lpt_load(lpt + LPT_MODE);
     if (mode == LPT_UNDECIDED) {
         const uint32_t want = lpt_load(lpt + LPT_READY) ? LPT_SORTED : LPT_NATURAL;
         const uint32_t old = atomicCAS(lpt + LPT_MODE, (uint32_t)LPT_UNDECIDED, want);
         mode = old != LPT_UNDECIDED ? old : want;
     }
     if (mode != LPT_SORTED) return i;
-    __threadfence();
+    /* No fence here (an agent-scope fence per decoded job writes back and invalidates the caches under every ray of the
+       wave: -11 % on the dwarf room).  None is needed: the start offsets and the lists were written through to memory
+       (agent-scope stores) before READY was, and no cache can hold an older copy of them -- nothing reads them before
+       SORTED is decided, and SORTED is only decided after READY was seen. */
     const uint32_t *start = lpt + LPT_START;
     uint32_t lo = 0u, hi = kLptBuckets - 1u; /* the bucket k with start[k] <= i that is smallest (buckets of equal start are empty but for the last) */
     while (lo < hi) {
@@ -1577,14 +1609,14 @@ ORT_D void pt_lane(const SceneView &sv, const RenderHot &rv, const float4 *tab, 
  * The plain loop (pt_lane) leaves the traversal loop when fewer than refill_below lanes are still tracing; those
  * stragglers then sit idle through the whole shading pass, and the next traversal loop runs for them and the few
  * new rays that need more than the root.  Here the stragglers are PARKED instead: path, hit and traversal state
- * (28 dwords) plus the used part of the LDS stack go to the wave's own L stash in HBM, and the lane takes a parked
+ * (kStashVecs float4 = 36 dwords) plus the used part of the LDS stack go to the wave's own L stash in HBM, and the lane takes a parked
  * path whose ray is finished (R stash) or a new job, so that the shading pass runs with all 64 lanes.  When enough
  * rays are parked, the wave parks its finished paths in R, fills ALL lanes from L and traverses -- 64 rays of the
  * expensive kind together, topping up from L as they finish.  Path state travels with the ray, seeds belong to
  * jobs, so which lane or in which order a path is advanced cannot change a bit of the result.
  * Both stashes are private to the wave (wave-uniform tops, ballot-prefix slots): no atomics, no barriers. */
 struct Stash {
-    float4 *rec;    /* [7][cap] */
+    float4 *rec;    /* [kStashVecs][cap] */
     uint32_t *stk;  /* [kLdsStack][cap], L only */
     uint32_t cap;
 };
@@ -1594,6 +1626,7 @@ ORT_D uint32_t lane_rank(unsigned long long mask) { /* set bits of mask below th
 }
 
 constexpr uint32_t kStashVecs = 9u; /* float4 per parked path */
+static_assert(kLdsStack % 4 == 0, "the L stash carves its stack words out of float4 units (kLdsStack / 4 per parked path)");
 ORT_D void stash_store(const Stash &st, uint32_t slot, const PathState &P, const HitState &h, uint32_t cur, int sp, V3 inv_d, const float *focal_cache,
                        uint32_t info_chain = 0u, uint32_t info_mat = 0u) {
     float4 *r = st.rec + slot;
