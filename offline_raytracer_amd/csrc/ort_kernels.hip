@@ -19,6 +19,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -154,28 +155,24 @@ struct RenderView {
     uint32_t park_min;   /* stragglers are parked only when there are at least this many of them (fewer: they idle through one shading pass, cheaper than an exchange step) */
     uint32_t inflight_cap; /* a lane without a path starts a new job only while the wave holds fewer parked paths than this
                               (every parked path is a job in progress: the more a wave holds, the longer its tail) */
-    /* expensive-blocks-first issue of the last lpt_chunks chunks (CHUNK policy, lpt_order below): u32 words in HBM,
-       [kLptHdr header][per local block: finished chunk-0 jobs << 24 | their bounces][kLptBuckets lists of my_blocks] */
-    uint32_t *lpt;
-    uint32_t lpt_chunks;
+    uint32_t block_major; /* CHUNK policy: the job space is [block][chunk][pixel] (see below) instead of [chunk][block][pixel] */
+    unsigned long long endgame_from; /* ray exchange: job index from which waves stop parking and drain their stashes (pt_lane_x) */
+    unsigned long long *drain; /* diagnostics (ORT_DEBUG_DRAIN): when each wave ran out of work (s_memrealtime), [workgroup * 4 + wave] */
 };
 
-/* ---- the tail of a launch, and the order of its last jobs --------------------------------------------------------
- * A job is a serial stream of `chunk` samples that only one lane can advance, so a launch ends one job length after
- * its job counter runs dry: the lanes that drew an expensive job last (a bunny pixel costs several wall pixels) finish
- * it alone.  Measured (profiles/r03_scaling_proxy.json): 12-19 ms on the 57 ms an 8-way shard of the headline frame
- * needs, proportional to the job length.  The job space is [chunk][block][pixel]; every chunk of a pixel costs about the
- * same, so chunk 0 -- finished long before the end of the launch -- tells what each 8x8 block costs (bounces counted per
- * job in LDS, summed per block), and the LAST lpt_chunks chunks (about four jobs per lane: on an 8-way shard one chunk is
- * one job per lane, and a single sorted round would still end with its most expensive job) are issued as ONE sequence
- * [block, most expensive first][chunk][pixel]: longest processing time first, the jobs drawn last are the cheapest.
- * Which lane renders which job, and when, cannot change a bit of the image (seeds belong to jobs); the permutation is a
- * bijection whatever the costs say, because every block is entered into exactly one bucket list exactly once (by the
- * lane that finishes its 64th chunk-0 job).
- * Header words: */
-constexpr uint32_t kLptBuckets = 64;
-enum : uint32_t { LPT_BLOCKS_DONE = 0, LPT_READY = 1, LPT_MODE = 2, LPT_COUNT = 32, LPT_START = 32 + kLptBuckets, kLptHdr = 32 + 2 * kLptBuckets };
-enum : uint32_t { LPT_UNDECIDED = 0, LPT_SORTED = 1, LPT_NATURAL = 2 };
+/* ---- the order in which a CHUNK render issues its jobs ----------------------------------------------------------
+ * A job is a serial stream of `chunk` samples that only one lane can advance.  The policy defines the job SET -- chunk k
+ * of pixel i, seeded by (k, i) -- not an order, and seeds belong to jobs, so the order of issue cannot change a bit of
+ * the image.  Issued chunk-major ([chunk][block][pixel], rounds 1-2) a launch ended with a sweep over the whole image in
+ * which the last lanes to draw an expensive job (a bunny pixel costs eight wall pixels) finished it alone: 12-19 ms on
+ * the 57 ms an 8-way shard of the headline frame needs (profiles/r03_scaling_proxy.json, r03_tuning.md).  Now
+ * BLOCK-major, [block][chunk][pixel]: all chunks of an 8x8 block are issued together, so the lanes of a wave work on the
+ * same few pixels with different seeds -- like rays, like costs, jobs that end together -- and the launch ends on its last
+ * BLOCKS, not on a last pass over everything: 8-way shard 70.8 -> 64.6 ms, plain loop on the whole frame 496 -> 461 ms.
+ * Issuing the blocks most expensive first on top of that (longest processing time first) was built twice and bought
+ * nothing: measured and sorted inside the launch, the lists are never ready in time (the expensive blocks are exactly the
+ * ones whose measuring jobs end last); measured by one render and used by the next, an 8-way shard took 65.6 ms against
+ * 65.2 in natural block order (profiles/r03_tuning.md).  Natural block order it is: no state, no atomics. */
 
 /* What the kernels receive by value: the handful of render parameters every ray reads; everything else stays in the
    RenderView in HBM behind `c` (job decoding, pixel addresses, stashes: read once per job or per pixel).  By value the
@@ -208,7 +205,7 @@ struct WfView {
    scene -- reads it again at every render.  -1 = not set: the launch policy decides. */
 struct Knobs {
     uint32_t force_fallback_mask = 0xffffffffu; /* ORT_DEBUG_FORCE_FALLBACK */
-    bool debug_util = false, debug_fallback = false; /* ORT_DEBUG_UTIL, ORT_DEBUG_FALLBACK */
+    bool debug_util = false, debug_fallback = false, debug_drain = false; /* ORT_DEBUG_UTIL, ORT_DEBUG_FALLBACK, ORT_DEBUG_DRAIN */
     int cache_resident = -1;   /* ORT_CACHE_RESIDENT */
     int refill_below = -1, descend_below = -1; /* ORT_REFILL_BELOW, ORT_DESCEND_BELOW */
     bool wavefront = false;    /* ORT_MODE=wavefront */
@@ -216,8 +213,9 @@ struct Knobs {
     int lds_tables = -1;       /* ORT_LDS_TABLES */
     int exchange = -1;         /* ORT_EXCHANGE */
     int long_min = -1, long_refill = -1, inflight_cap = -1, park_min = -1; /* ORT_LONG_MIN, ORT_LONG_REFILL, ORT_INFLIGHT_CAP, ORT_PARK_MIN */
-    int lpt = -1;              /* ORT_LPT: expensive-blocks-first issue of the last chunks: 0 off, n > 0 = that many chunks (default: ~4 jobs per lane) */
+    int lpt = -1;              /* ORT_LPT=0: CHUNK jobs issued chunk-major (rounds 1-2) instead of block-major */
     int wide = -1;             /* ORT_WIDE: 4-wide tree (default: for trees that leave the L2) */
+    int endgame_jobs = -1;     /* ORT_ENDGAME_JOBS: the ray exchange drains its stashes over the last n jobs per lane (x 1/4 job; default 8 = two jobs) */
     int blocks_per_cu = -1;    /* ORT_BLOCKS_PER_CU (takes effect at upload) */
 };
 static int env_int(const char *name, int unset = -1) {
@@ -230,6 +228,7 @@ static Knobs read_knobs() {
     if ((e = getenv("ORT_DEBUG_FORCE_FALLBACK"))) k.force_fallback_mask = (uint32_t)strtoul(e, nullptr, 0);
     k.debug_util = getenv("ORT_DEBUG_UTIL") != nullptr;
     k.debug_fallback = getenv("ORT_DEBUG_FALLBACK") != nullptr;
+    k.debug_drain = getenv("ORT_DEBUG_DRAIN") != nullptr;
     k.cache_resident = env_int("ORT_CACHE_RESIDENT");
     k.refill_below = env_int("ORT_REFILL_BELOW");
     k.descend_below = env_int("ORT_DESCEND_BELOW");
@@ -243,6 +242,7 @@ static Knobs read_knobs() {
     k.park_min = env_int("ORT_PARK_MIN");
     k.lpt = env_int("ORT_LPT");
     k.wide = env_int("ORT_WIDE");
+    k.endgame_jobs = env_int("ORT_ENDGAME_JOBS");
     k.blocks_per_cu = env_int("ORT_BLOCKS_PER_CU");
     return k;
 }
@@ -281,8 +281,8 @@ struct DeviceScene {
     int cu_count = 0;
     void *stash = nullptr; /* ray exchange: the waves' stashes */
     size_t stash_bytes = 0;
-    void *lpt = nullptr;   /* cost-ordered issue of the last chunk (RenderView::lpt) */
-    size_t lpt_bytes = 0;
+    void *drain = nullptr; /* ORT_DEBUG_DRAIN: per-wave end times */
+    size_t drain_bytes = 0;
     void *wf_mem = nullptr; /* wavefront state, carved into the WfView arrays */
     size_t wf_bytes = 0;
     unsigned long long *h_active = nullptr; /* pinned */
@@ -740,7 +740,8 @@ ORT_D void reset_hit(HitState &h, float best_t) {
 
 /* the analytic prologue (ort_tree.cpp): the lanes that start a ray now all test the same shape at the same
    time -- uniform addresses, no divergence -- and enter the tree with best_t already set */
-template <bool COUNTERS, bool TABS>
+/* HAS_EXCL: the re-traversals of resolve_hit ignore one shape (excl); a ray's first traversal ignores none */
+template <bool COUNTERS, bool TABS, bool HAS_EXCL = false>
 ORT_D void prologue_tests(const SceneView &sv, const float4 *tab, V3 org, V3 dir, V3 inv_d, HitState &h, Counters &c, uint32_t excl = kNoPrim) {
     /* TABS: the shapes' records come from the LDS tables */
     const float4 *pb = tab + kTabPro, *ps = pb + 2u * sv.pro_boxes, *pc = ps + sv.pro_spheres;
@@ -760,9 +761,9 @@ ORT_D void prologue_tests(const SceneView &sv, const float4 *tab, V3 org, V3 dir
             float4 lo, hi;
             if (TABS) { lo = pb[2u * i]; hi = pb[2u * i + 1u]; } else { lo = sv.boxes[2u * i]; hi = sv.boxes[2u * i + 1u]; }
             const uint32_t prim = ((uint32_t)PRIM_BOX << 28) | i;
-            if (COUNTERS && prim != excl) c.analytic++;
+            if (COUNTERS && (!HAS_EXCL || prim != excl)) c.analytic++;
             float t = hit_aab_t_finite(mk(lo.x, lo.y, lo.z), mk(hi.x, hi.y, hi.z), org, inv_d);
-            if (ORT_RARE(prim == excl)) t = -1.0f;
+            if (HAS_EXCL && ORT_RARE(prim == excl)) t = -1.0f;
             bool take = (t >= kHitTMin && t < h.best_t);
             if (ORT_RARE(t == h.best_t && t >= kHitTMin && h.hit_prim != kNoPrim))
                 take = prim_order(sv, PRIM_BOX, i) < prim_order(sv, h.hit_prim >> 28, h.hit_prim & 0x00ffffffu);
@@ -964,58 +965,6 @@ ORT_D V3 focal_point(const RenderHot &rv, uint32_t pxy, V3 cam_p, V3 cam_x, V3 c
     return add(cam_p, scale(focal_length, to_pixel));
 }
 
-#ifndef ORT_HOST_SIM
-ORT_D uint32_t lpt_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-ORT_D void lpt_store(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-/* a chunk-0 job of local block lb has ended (or was skipped: pixel outside the rect) with `bounces` rays cast beyond
-   its primaries.  ONE atomic per job: the block's word counts jobs in its top byte and bounces below.  The lane that
-   ends the block's 64th job files the block under its cost; the lane that files the last block publishes the lists. */
-ORT_D void lpt_job_done(uint32_t *lpt, uint32_t my_blocks, uint32_t per_bucket, uint32_t lb, uint32_t bounces) {
-    uint32_t *acc = lpt + kLptHdr, *lists = acc + my_blocks;
-    bounces = bounces < 0x3ffffu ? bounces : 0x3ffffu; /* 64 jobs stay below 2^24 */
-    const uint32_t old = atomicAdd(acc + lb, (1u << 24) | bounces);
-    if ((old >> 24) != 63u) return;
-    uint32_t b = ((old & 0x00ffffffu) + bounces) / per_bucket;
-    b = b < kLptBuckets ? b : kLptBuckets - 1u;
-    const uint32_t slot = atomicAdd(lpt + LPT_COUNT + b, 1u);
-    lpt_store(lists + (size_t)b * my_blocks + slot, lb);
-    __threadfence(); /* the list entry before the count of filed blocks */
-    if (atomicAdd(lpt + LPT_BLOCKS_DONE, 1u) != my_blocks - 1u) return;
-    uint32_t at = 0; /* most expensive bucket first */
-    for (uint32_t k = kLptBuckets; k-- > 0u;) {
-        lpt_store(lpt + LPT_START + k, at);
-        at += lpt_load(lpt + LPT_COUNT + k);
-    }
-    __threadfence();
-    lpt_store(lpt + LPT_READY, 1u);
-}
-/* the i-th block of the sorted part of the job space: by descending cost when the lists were complete before its first
-   job was decoded (decided once, by whoever decodes first: every lane must use the same order), else in natural order.
-   Once published the lists never change: they are read with ordinary (cached) loads, the
-   bucket by bisection over the 64 start offsets (START falls from bucket 0 to bucket 63, 0 at the most expensive). */
-ORT_D uint32_t lpt_order(uint32_t *lpt, uint32_t my_blocks, uint32_t i) {
-    uint32_t mode = lpt[LPT_MODE]; /* an ordinary load: a decision, once seen, is final; a stale "undecided" only leads to the atomics below */
-    if (mode == LPT_UNDECIDED) mode = lpt_load(lpt + LPT_MODE);
-    if (mode == LPT_UNDECIDED) {
-        const uint32_t want = lpt_load(lpt + LPT_READY) ? LPT_SORTED : LPT_NATURAL;
-        const uint32_t old = atomicCAS(lpt + LPT_MODE, (uint32_t)LPT_UNDECIDED, want);
-        mode = old != LPT_UNDECIDED ? old : want;
-    }
-    if (mode != LPT_SORTED) return i;
-    /* No fence here (an agent-scope fence per decoded job writes back and invalidates the caches under every ray of the
-       wave: -11 % on the dwarf room).  None is needed: the start offsets and the lists were written through to memory
-       (agent-scope stores) before READY was, and no cache can hold an older copy of them -- nothing reads them before
-       SORTED is decided, and SORTED is only decided after READY was seen. */
-    const uint32_t *start = lpt + LPT_START;
-    uint32_t lo = 0u, hi = kLptBuckets - 1u; /* the bucket k with start[k] <= i that is smallest (buckets of equal start are empty but for the last) */
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (start[mid] <= i) hi = mid; else lo = mid + 1u;
-    }
-    return lpt[kLptHdr + my_blocks + (size_t)lo * my_blocks + (i - start[lo])];
-}
-#endif
-
 /* Advance the lane's path state machine until it has produced the next ray (returns true; the ray
    is P.org / P.dir) or has run out of work (returns false).  On entry with P.ps == PS_HIT, h holds
    the resolved closest hit of the ray produced by the previous call. */
@@ -1023,7 +972,7 @@ ORT_D uint32_t lpt_order(uint32_t *lpt, uint32_t my_blocks, uint32_t i) {
    samples): the job's rect, its sample count and its index then need no registers of their own */
 template <bool COUNTERS, bool DIFFUSE = false, bool TABS = false, bool IMPLICIT = false>
 ORT_D bool produce_ray(const SceneView &sv, const RenderHot &rv, const float4 *tab, PathState &P, const HitState &h, Counters &c, Prof &pr,
-                       float *focal_cache = nullptr, int focal_stride = 0, uint32_t spp_u = 0) {
+                       float *focal_cache = nullptr, int focal_stride = 0, uint32_t spp_u = 0, uint32_t *late_flag = nullptr) {
     const V3 cam_p = mk(sv.cam[0], sv.cam[1], sv.cam[2]);
     const V3 cam_x = mk(sv.cam[3], sv.cam[4], sv.cam[5]);
     const V3 cam_y = mk(sv.cam[6], sv.cam[7], sv.cam[8]);
@@ -1091,7 +1040,6 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderHot &rv, const float4 *t
                     if (is_sphere) { rng_step(P.rng); rng_step(P.rng); rng_step(P.rng); rng_step(P.rng); }
                 }
                 ORT_UTIL(sv, 6, true);
-                if (IMPLICIT && focal_cache) ((uint32_t *)focal_cache)[3 * focal_stride] += 1u; /* this job's bounces: what its block costs (lpt_job_done) */
                 draw = sample_brdf_draw<DIFFUSE>(P.rng, kRoughness, m);
                 angle = draw.phi;
             } else {
@@ -1113,12 +1061,6 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderHot &rv, const float4 *t
                 p[0] = o.x; p[1] = o.y; p[2] = o.z;
                 if (IMPLICIT) {
                     P.ps = PS_NEED_JOB; /* a one-pixel job ends with its pixel */
-#ifndef ORT_HOST_SIM
-                    if (rv.mode == JOBS_CHUNK && (P.jyp >> 16) == 0u && focal_cache) {
-                        uint32_t *lpt = rv.c->lpt;
-                        if (lpt) lpt_job_done(lpt, rv.c->my_blocks, 8u * job_spp, (uint32_t)(packed_index(rv, px, py) >> 6), ((const uint32_t *)focal_cache)[3 * focal_stride]);
-                    }
-#endif
                 } else {
                 px++;
                 if (px == (P.jxx >> 16)) { px = P.jxx & 0xffffu; py++; }
@@ -1134,6 +1076,7 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderHot &rv, const float4 *t
             if (P.ps == PS_NEED_JOB) {
                 unsigned long long j = ORT_NEXT_JOB(rv.c->next_job);
                 if (j >= rv.c->job_count) { P.ps = PS_DONE; break; }
+                if (IMPLICIT && late_flag && j >= rv.c->endgame_from) *late_flag = 1u; /* ray exchange: the launch is near its end (pt_lane_x) */
                 if (!IMPLICIT && rv.mode == JOBS_EXPLICIT) {
                     ort_tile_job jb = rv.c->jobs[j];
                     P.job_index = (uint32_t)j;
@@ -1148,34 +1091,23 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderHot &rv, const float4 *t
                 } else {
                     /* implicit job space: [chunk k][my 8x8 block b][pixel-in-block p] */
                     unsigned long long per_chunk = (unsigned long long)rv.c->my_blocks * 64ull;
-                    uint32_t k = (uint32_t)(j / per_chunk);
-                    uint32_t rem = (uint32_t)(j % per_chunk);
-                    uint32_t lb = rem >> 6; /* local block */
-                    uint32_t pin = rem & 63u;
-#ifndef ORT_HOST_SIM
-                    uint32_t *lpt = (IMPLICIT && rv.mode == JOBS_CHUNK && focal_cache) ? rv.c->lpt : nullptr;
-                    if (lpt) {
-                        /* the last lpt_chunks chunks form one sequence [block by descending cost][chunk][pixel] */
-                        const uint32_t nsort = rv.c->lpt_chunks, k0 = rv.c->nchunks - nsort;
-                        if (k >= k0) {
-                            const unsigned long long i = j - (unsigned long long)k0 * per_chunk;
-                            const uint32_t per_block = nsort * 64u;
-                            const uint32_t within = (uint32_t)(i % per_block);
-                            lb = lpt_order(lpt, rv.c->my_blocks, (uint32_t)(i / per_block));
-                            k = k0 + (within >> 6);
-                            pin = within & 63u;
-                        }
+                    uint32_t k, lb, pin; /* chunk, local block, pixel in block */
+                    if (rv.c->block_major) {
+                        const uint32_t per_block = rv.c->nchunks * 64u;
+                        const uint32_t within = (uint32_t)(j % per_block);
+                        lb = (uint32_t)(j / per_block);
+                        k = within >> 6;
+                        pin = within & 63u;
+                    } else {
+                        k = (uint32_t)(j / per_chunk);
+                        const uint32_t rem = (uint32_t)(j % per_chunk);
+                        lb = rem >> 6;
+                        pin = rem & 63u;
                     }
-#endif
                     uint32_t blk = rv.c->shard_index + lb * rv.c->shard_count;
                     int x = (int)((rv.c->block_x0 + blk % rv.c->blocks_w) * 8u + (pin & 7u));
                     int y = (int)((rv.c->block_y0 + blk / rv.c->blocks_w) * 8u + (pin >> 3));
-                    if (x < rv.c->x0 || x >= rv.c->x1 || y < rv.c->y0 || y >= rv.c->y1) {
-#ifndef ORT_HOST_SIM
-                        if (lpt && k == 0u) lpt_job_done(lpt, rv.c->my_blocks, 8u * rv.c->chunk, lb, 0u); /* skipped jobs count towards their block's 64 */
-#endif
-                        continue;
-                    }
+                    if (x < rv.c->x0 || x >= rv.c->x1 || y < rv.c->y0 || y >= rv.c->y1) continue;
                     uint32_t pix = (uint32_t)(y * rv.W + x);
                     if (!IMPLICIT) P.jxx = (uint32_t)x | ((uint32_t)(x + 1) << 16);
                     P.pxy = (uint32_t)x | ((uint32_t)y << 16);
@@ -1199,7 +1131,6 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderHot &rv, const float4 *t
                 if (focal_cache) { /* the pixel's focal point, once per pixel (persistent kernel: three floats of LDS per lane) */
                     V3 f = focal_point(rv, P.pxy, cam_p, cam_x, cam_y, cam_z, focal_length);
                     focal_cache[0] = f.x; focal_cache[focal_stride] = f.y; focal_cache[2 * focal_stride] = f.z;
-                    if (IMPLICIT) ((uint32_t *)focal_cache)[3 * focal_stride] = 0u; /* a one-pixel job starts: its bounce count */
                 }
             }
             if (P.sample == job_spp) continue; /* spp == 0: the reference's sample loop runs zero times */
@@ -1531,7 +1462,7 @@ ORT_D void resolve_hit(const SceneView &sv, const float4 *tab, V3 org, V3 dir, V
                 t2.cur = 0; t2.sp = 0; t2.inv_d = inv_d;
                 /* CH_UNKNOWN: only hits at or before the leaf box's entry matter (the hit tests' "<" must accept t == gap) */
                 reset_hit(h, verdict == CH_REJECT ? 3.402823466e+38f : om_bits_f32(om_f32_bits(gap) + 1u));
-                prologue_tests<COUNTERS, TABS>(sv, tab, org, dir, inv_d, h, c, w_prim);
+                prologue_tests<COUNTERS, TABS, true>(sv, tab, org, dir, inv_d, h, c, w_prim);
                 (void)traverse<COUNTERS, LDS_ENTRIES - 4, BLOCK, false, false, WIDE>(sv, org, dir, t2, h, lds_stack, spill, tid, 0, 0, c, pr, w_prim);
                 if (verdict == CH_UNKNOWN) {
                     if (h.hit_prim != kNoPrim || h.phantom_t <= gap) {
@@ -1686,8 +1617,18 @@ ORT_D void pt_lane_x(const SceneView &sv, const RenderHot &rv, const float4 *tab
     R.rec = wbase + (kStashVecs + (uint32_t)kLdsStack / 4u) * rv.c->capL; R.cap = rv.c->capR; R.stk = nullptr;
     uint32_t ltop = 0, rtop = 0; /* wave-uniform */
     float *focal_cache = lds_focal + tid;
+    /* the wave stops parking, and hands its parked paths to free lanes before new jobs, as soon as one of its lanes has
+       drawn a job beyond endgame_from: every parked path is a job in progress, and the oldest ones lie at the bottom of the
+       LIFO stashes until something drains them -- left to the very end they are a second tail after the job space is empty.
+       The lane that draws such a job raises a word of its own in LDS (produce_ray); the wave looks at the 64 words once per
+       exchange step.  (Looking at the job counter itself, one lane every 16th step, halved the kernel's speed: 4 096 waves
+       reading the one line every job draw of the chip goes through.) */
+    uint32_t *late_flag = (uint32_t *)lds_focal + 3 * kBlock + tid;
+    *late_flag = 0u;
+    bool early_end = false;
 
     for (;;) {
+        if (!early_end) early_end = __ballot(*(volatile uint32_t *)late_flag != 0u) != 0ull;
         /* ---- exchange: every lane is tracing (unfinished ray), done (finished ray, PS_HIT) or free (no path) ---- */
         const unsigned long long m_tr = __ballot(tracing);
         const unsigned long long m_done = __ballot(!tracing && P.ps == PS_HIT);
@@ -1697,7 +1638,7 @@ ORT_D void pt_lane_x(const SceneView &sv, const RenderHot &rv, const float4 *tab
         const bool drain = m_tr == 0ull && m_done == 0ull && rtop == 0u && __ballot(P.ps != PS_DONE) == 0ull;
         /* once the job space is empty nothing is parked any more (every parked path is a job some lane still has to
            finish): lanes without a path take parked ones, finished rays first, and everything else carries on */
-        const bool endgame = __ballot(P.ps == PS_DONE) != 0ull;
+        const bool endgame = early_end || __ballot(P.ps == PS_DONE) != 0ull;
         bool long_phase = !endgame && ltop > 0u && (n_tr + ltop >= rv.c->long_min || drain);
         if (endgame) {
             const bool is_free = !tracing && P.ps != PS_HIT;
@@ -1783,7 +1724,7 @@ ORT_D void pt_lane_x(const SceneView &sv, const RenderHot &rv, const float4 *tab
             ORT_PHASE(pr, sv, 7, true);
             if (P.ps == PS_HIT) resolve_hit<COUNTERS, TABS, kLdsStack, kBlock, true>(sv, tab, P.org, P.dir, T.inv_d, lane_id, h, c, pr, lds_stack, spill, tid);
             ORT_PHASE(pr, sv, 0, P.ps == PS_HIT);
-            tracing = produce_ray<COUNTERS, DIFFUSE, TABS, true>(sv, rv, tab, P, h, c, pr, focal_cache, kBlock, spp_u);
+            tracing = produce_ray<COUNTERS, DIFFUSE, TABS, true>(sv, rv, tab, P, h, c, pr, focal_cache, kBlock, spp_u, late_flag);
             if (tracing) {
                 begin_ray<COUNTERS, TABS, kLdsStack, kBlock>(sv, tab, P, T, h, c, pr, lds_stack, spill, tid);
                 if (COUNTERS) c.rays++;
@@ -1896,7 +1837,7 @@ template <bool COUNTERS, bool DIFFUSE, bool TABS, bool IMPLICIT = false, bool WI
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(ORT_WAVES_PER_EU, ORT_WAVES_PER_EU)))
 pt_persistent(SceneView sv, RenderHot rv) {
     __shared__ uint32_t lds_stack[kLdsStack * kBlock];
-    __shared__ float lds_focal[4 * kBlock]; /* focal[component][lane]; row 3: bounces of the lane's current job (u32) */
+    __shared__ float lds_focal[3 * kBlock]; /* focal[component][lane] */
     __shared__ float4 lds_tab[TABS ? kTabF4 : 1];
     if (TABS) fill_tab(sv, lds_tab);
     const bool prof = COUNTERS && sv.util != nullptr && blockIdx.x < 32u;
@@ -1906,6 +1847,7 @@ pt_persistent(SceneView sv, RenderHot rv) {
         __syncthreads();
     }
     pt_lane<COUNTERS, DIFFUSE, TABS, IMPLICIT, WIDE>(sv, rv, lds_tab, lds_stack, lds_focal, (int)threadIdx.x, blockIdx.x * (uint32_t)kBlock + threadIdx.x, prof);
+    if ((threadIdx.x & 63u) == 0u && rv.c->drain) rv.c->drain[blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memrealtime();
     if (prof) {
         __syncthreads();
         if (threadIdx.x < 96 && g_lds_prof[threadIdx.x]) atomicAdd(sv.util + threadIdx.x, g_lds_prof[threadIdx.x]);
@@ -1917,7 +1859,7 @@ template <bool COUNTERS, bool DIFFUSE>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(ORT_WAVES_PER_EU, ORT_WAVES_PER_EU)))
 pt_persistent_x(SceneView sv, RenderHot rv) {
     __shared__ uint32_t lds_stack[kLdsStack * kBlock];
-    __shared__ float lds_focal[4 * kBlock];
+    __shared__ float lds_focal[4 * kBlock]; /* rows 0-2 focal point, row 3 "this lane drew a job near the end of the launch" (u32) */
     __shared__ float4 lds_tab[kTabF4];
     fill_tab(sv, lds_tab);
     const bool prof = COUNTERS && sv.util != nullptr && blockIdx.x < 32u;
@@ -1927,6 +1869,7 @@ pt_persistent_x(SceneView sv, RenderHot rv) {
         __syncthreads();
     }
     pt_lane_x<COUNTERS, DIFFUSE, true>(sv, rv, lds_tab, lds_stack, lds_focal, (int)threadIdx.x, blockIdx.x * (uint32_t)kBlock + threadIdx.x, prof);
+    if ((threadIdx.x & 63u) == 0u && rv.c->drain) rv.c->drain[blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memrealtime();
     if (prof) {
         __syncthreads();
         if (threadIdx.x < 96 && g_lds_prof[threadIdx.x]) atomicAdd(sv.util + threadIdx.x, g_lds_prof[threadIdx.x]);
@@ -2078,7 +2021,7 @@ void device_release(Scene *scene) {
         if (p) (void)hipFree(p);
     if (d->wf_mem) (void)hipFree(d->wf_mem);
     if (d->stash) (void)hipFree(d->stash);
-    if (d->lpt) (void)hipFree(d->lpt);
+    if (d->drain) (void)hipFree(d->drain);
     if (d->h_active) (void)hipHostFree(d->h_active);
     if (d->ev0) (void)hipEventDestroy(d->ev0);
     if (d->ev1) (void)hipEventDestroy(d->ev1);
@@ -2430,10 +2373,12 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
         /* ray exchange (pt_lane_x): bit-identical; 60 of 64 lanes in the shading pass instead of 53 and leaf
            visits four times better filled, against the parking traffic.  On by itself where it is a gain
            (profiles/r02_tuning.md): the diffuse flavour (the all-lobes one spills too much around the exchange) on
-           launches of at least 24 jobs per lane -- every parked path is a job in progress, so a wave's tail grows with
-           what it has parked, which short launches and 8-way shards cannot amortise.  ORT_EXCHANGE=0 / 1 forces it. */
+           launches of at least 48 jobs per lane -- every parked path is a job in progress, so a wave's tail grows with
+           what it has parked, which short launches and 4- or 8-way shards cannot amortise (round 3, with the sorted issue of
+           the job space: a 4-way shard of the headline frame, 32 jobs per lane, 120.8 ms plain / 122.5 with the exchange; a
+           2-way shard, 63 per lane, 232.8 / 225.6).  ORT_EXCHANGE=0 / 1 forces it. */
         /* ... and not for trees that leave the L2 (the 1M-triangle scene: 1 268 with it, 1 272 without) */
-        const bool worth_it = diffuse && cache_resident_tree && rv.job_count >= 24ull * (unsigned long long)grid * kBlock;
+        const bool worth_it = diffuse && cache_resident_tree && rv.job_count >= 48ull * (unsigned long long)grid * kBlock;
         exch = tabs && rv.mode != JOBS_EXPLICIT && (kn.exchange >= 0 ? kn.exchange != 0 : worth_it) && (!counters || (want_util && diffuse));
         if (exch && kn.refill_below < 0) rv.refill_below = 16; /* stragglers park instead of idling: leave the loop a little earlier */
         if (exch) {
@@ -2449,27 +2394,25 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
                on what it has parked (parked + tracing >= long_min), or nothing in it could ever move again */
             if (rv.inflight_cap < rv.long_min) rv.inflight_cap = rv.long_min;
             if (rv.inflight_cap < 1u) rv.inflight_cap = 1u;
+            {
+                const unsigned long long quarter_jobs = kn.endgame_jobs >= 0 ? (unsigned long long)kn.endgame_jobs : 8ull;
+                const unsigned long long tail_jobs = quarter_jobs * (unsigned long long)grid * kBlock / 4ull;
+                rv.endgame_from = rv.job_count > tail_jobs ? rv.job_count - tail_jobs : 0ull;
+            }
             rv.stash_wave_f4 = (kStashVecs + (uint32_t)kLdsStack / 4u) * rv.capL + kStashVecs * rv.capR;
             const size_t need = (size_t)d->max_blocks * (kBlock / 64) * rv.stash_wave_f4 * sizeof(float4);
             if ((rc = ensure(&d->stash, &d->stash_bytes, need, err))) return rc;
             rv.stash = (float4 *)d->stash;
         }
     }
-    /* expensive-blocks-first issue of the last chunk (lpt_order): CHUNK renders of at least four chunks, so that chunk 0,
-       whose jobs measure the blocks, is long finished when the last chunk is issued (if it is not, the kernel notices and
-       keeps the natural order).  ORT_LPT=0 switches it off (A/B runs; same image either way). */
-    if (!wavefront && rv.mode == JOBS_CHUNK && rv.nchunks >= 4u && rv.my_blocks > 0u && kn.lpt != 0) {
-        const size_t words = (size_t)kLptHdr + (size_t)(1u + kLptBuckets) * rv.my_blocks;
-        if ((rc = ensure(&d->lpt, &d->lpt_bytes, words * sizeof(uint32_t), err))) return rc;
-        ORT_HIP(hipMemsetAsync(d->lpt, 0, ((size_t)kLptHdr + (size_t)rv.my_blocks) * sizeof(uint32_t), stream));
-        rv.lpt = (uint32_t *)d->lpt;
-        /* as many chunks as give every lane about four sorted jobs, at least one, and never the first two chunks (chunk 0
-           measures; its last jobs must have ended before the first sorted job is decoded) */
-        const unsigned long long lanes = (unsigned long long)d->max_blocks * kBlock, per_chunk = (unsigned long long)rv.my_blocks * 64ull;
-        unsigned long long want = kn.lpt > 0 ? (unsigned long long)kn.lpt : (4ull * lanes + per_chunk - 1ull) / per_chunk;
-        if (want < 1ull) want = 1ull;
-        if (want > rv.nchunks - 2u) want = rv.nchunks - 2u;
-        rv.lpt_chunks = (uint32_t)want;
+    /* CHUNK renders issue their jobs block-major (see "the order in which a CHUNK render issues its jobs"); ORT_LPT=0:
+       chunk-major as in rounds 1-2 (A/B runs; same image either way) */
+    if (rv.mode == JOBS_CHUNK && rv.nchunks >= 2u && kn.lpt != 0) rv.block_major = 1u;
+    if (kn.debug_drain && stats && !wavefront) {
+        const size_t bytes = (size_t)d->max_blocks * (kBlock / 64) * sizeof(unsigned long long);
+        if ((rc = ensure(&d->drain, &d->drain_bytes, bytes, err))) return rc;
+        ORT_HIP(hipMemsetAsync(d->drain, 0, bytes, stream));
+        rv.drain = (unsigned long long *)d->drain;
     }
     /* the RenderView goes to HBM (pageable source: the copy is staged before the call returns); the kernels get the few
        fields every ray reads by value and a pointer to the rest */
@@ -2537,6 +2480,22 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
         ORT_HIP(hipMemcpy(dg, d->ctrl + 6 + kDiagFallback, sizeof(dg), hipMemcpyDeviceToHost));
         fprintf(stderr, "fallback: %llu rays traversed again without their first winner, %llu re-cast exactly (%llu octree nodes enqueued, %llu busy queues met)\n",
                 dg[1], fb[0], dg[0], dg[2]);
+        fprintf(stderr, "issue order: %s\n", rv.block_major ? "block-major" : "chunk-major");
+    }
+    if (stats && rv.drain) { /* developer diagnostics: how the launch drains */
+        std::vector<unsigned long long> t((size_t)grid * (kBlock / 64));
+        ORT_HIP(hipMemcpy(t.data(), rv.drain, t.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        unsigned long long last = 0;
+        for (unsigned long long v : t) last = v > last ? v : last;
+        const double tick_ms = 1e-5; /* s_memrealtime: 100 MHz */
+        const double marks[] = {0.25, 0.5, 1, 2, 3, 5, 8, 12, 20};
+        fprintf(stderr, "drain: of %zu waves, still running before the end of the launch:", t.size());
+        for (double m : marks) {
+            size_t n = 0;
+            for (unsigned long long v : t) n += (double)(last - v) * tick_ms < m ? 1 : 0;
+            fprintf(stderr, "  %g ms: %zu", m, n);
+        }
+        fprintf(stderr, "\n");
     }
     if (stats) {
         memset(stats, 0, sizeof(*stats));

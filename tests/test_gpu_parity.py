@@ -231,31 +231,30 @@ def test_wide_tree_equals_binary_tree(api, oracle, gpu_scene, monkeypatch, name,
     assert_bits_equal(b, ref, "wide tree vs oracle")
 
 
-def test_cost_ordered_issue_of_the_last_chunks(api, gpu_scene, monkeypatch):
-    """CHUNK renders issue their last chunks most-expensive-block first (lpt_order; chunk 0 measures the blocks): same
-    image with it on (default), off, and with 1 / 3 sorted chunks; whole frames, clipped rects and packed shards"""
+def test_issue_order_of_chunk_jobs_does_not_matter(api, gpu_scene, monkeypatch):
+    """CHUNK renders issue their jobs block-major -- [block][chunk][pixel]: all chunks of an 8x8 block together
+    (ort_kernels.hip, "the order in which a CHUNK render issues its jobs") -- instead of chunk-major as in rounds 1-2
+    (ORT_LPT=0).  Seeds belong to jobs, so the image is the same bit for bit: whole frames with ragged edge blocks, clipped
+    rects, 3-way shards, plain loop and ray exchange (whose waves stop parking near the end of the launch: ORT_ENDGAME_JOBS)"""
     scene = gpu_scene("c3_bunny_room")
-    w, h, spp, chunk, seed = 333, 187, 24, 2, 5  # 12 chunks, ragged edge blocks
+    w, h, spp, chunk, seed = 333, 187, 24, 2, 5  # 12 chunks
     monkeypatch.setenv("ORT_LPT", "0")
     a, _ = scene.render(w, h, spp, seed, "chunk", chunk=chunk)
-    for v in (None, "1", "3", "10"):
-        if v is None:
-            monkeypatch.delenv("ORT_LPT")
-        else:
-            monkeypatch.setenv("ORT_LPT", v)
+    for env in ({}, {"ORT_EXCHANGE": "1"}, {"ORT_EXCHANGE": "1", "ORT_ENDGAME_JOBS": "0"}, {"ORT_EXCHANGE": "1", "ORT_ENDGAME_JOBS": "64"}, {"ORT_EXCHANGE": "0"}):
+        monkeypatch.delenv("ORT_LPT", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
         b, _ = scene.render(w, h, spp, seed, "chunk", chunk=chunk)
-        assert_bits_equal(a, b, "ORT_LPT=%s" % v)
+        assert_bits_equal(a, b, "%s" % (env,))
         r, _ = scene.render(w, h, spp, seed, "chunk", chunk=chunk, rect=(37, 21, 290, 150))
-        assert_bits_equal(a[21:150, 37:290], r[21:150, 37:290], "clipped rect, ORT_LPT=%s" % v)
+        assert_bits_equal(a[21:150, 37:290], r[21:150, 37:290], "%s, clipped rect" % (env,))
         acc = np.zeros_like(a)
         for k in range(3):
             part, _ = scene.render(w, h, spp, seed, "chunk", chunk=chunk, shard=(k, 3))
             acc += part
-        assert_bits_equal(a, acc, "3-way shard union, ORT_LPT=%s" % v)
-    monkeypatch.setenv("ORT_EXCHANGE", "1")
-    monkeypatch.delenv("ORT_LPT", raising=False)
-    x, _ = scene.render(w, h, spp, seed, "chunk", chunk=chunk)
-    assert_bits_equal(a, x, "sorted issue with the ray exchange")
+        assert_bits_equal(a, acc, "%s, 3-way shard union" % (env,))
+        for k in env:
+            monkeypatch.delenv(k)
 
 
 def test_determinism(api, gpu_scene):

@@ -110,7 +110,7 @@ int main(int argc, char **argv) {
     if (getenv("SIM_DUMP_RNG")) { g_pixel_rng = pix_rng.data(); g_W = W; }
     std::vector<uint32_t> lds(kLdsStack * kBlock);
     auto t0 = std::chrono::steady_clock::now();
-    std::vector<float> lds_focal(4 * kBlock); /* row 3: the bounce count of the lane's job */
+    std::vector<float> lds_focal(3 * kBlock);
     std::vector<uint32_t> bfsq(scene->ref.nodes.size() + 8), bfs_lock(1, 0u);
     cold.bfs_pool = bfsq.data();
     cold.bfs_locks = bfs_lock.data();
