@@ -215,7 +215,7 @@ struct Knobs {
     int long_min = -1, long_refill = -1, inflight_cap = -1, park_min = -1; /* ORT_LONG_MIN, ORT_LONG_REFILL, ORT_INFLIGHT_CAP, ORT_PARK_MIN */
     int lpt = -1;              /* ORT_LPT=0: CHUNK jobs issued chunk-major (rounds 1-2) instead of block-major */
     int wide = -1;             /* ORT_WIDE: 4-wide tree (default: for trees that leave the L2) */
-    int endgame_jobs = -1;     /* ORT_ENDGAME_JOBS: the ray exchange drains its stashes over the last n jobs per lane (x 1/4 job; default 8 = two jobs) */
+    int endgame_jobs = -1;     /* ORT_ENDGAME_JOBS: the ray exchange drains its stashes over the last n/4 jobs per lane (default 16 = four jobs) */
     int blocks_per_cu = -1;    /* ORT_BLOCKS_PER_CU (takes effect at upload) */
 };
 static int env_int(const char *name, int unset = -1) {
@@ -972,7 +972,7 @@ ORT_D V3 focal_point(const RenderHot &rv, uint32_t pxy, V3 cam_p, V3 cam_x, V3 c
    samples): the job's rect, its sample count and its index then need no registers of their own */
 template <bool COUNTERS, bool DIFFUSE = false, bool TABS = false, bool IMPLICIT = false>
 ORT_D bool produce_ray(const SceneView &sv, const RenderHot &rv, const float4 *tab, PathState &P, const HitState &h, Counters &c, Prof &pr,
-                       float *focal_cache = nullptr, int focal_stride = 0, uint32_t spp_u = 0, uint32_t *late_flag = nullptr) {
+                       float *focal_cache = nullptr, int focal_stride = 0, uint32_t spp_u = 0, uint32_t *late_flag = nullptr, bool no_new_job = false) {
     const V3 cam_p = mk(sv.cam[0], sv.cam[1], sv.cam[2]);
     const V3 cam_x = mk(sv.cam[3], sv.cam[4], sv.cam[5]);
     const V3 cam_y = mk(sv.cam[6], sv.cam[7], sv.cam[8]);
@@ -1074,6 +1074,7 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderHot &rv, const float4 *t
                 }
             }
             if (P.ps == PS_NEED_JOB) {
+                if (no_new_job) return false; /* ray exchange, end of the launch: this lane takes a parked path first (pt_lane_x) */
                 unsigned long long j = ORT_NEXT_JOB(rv.c->next_job);
                 if (j >= rv.c->job_count) { P.ps = PS_DONE; break; }
                 if (IMPLICIT && late_flag && j >= rv.c->endgame_from) *late_flag = 1u; /* ray exchange: the launch is near its end (pt_lane_x) */
@@ -1724,7 +1725,10 @@ ORT_D void pt_lane_x(const SceneView &sv, const RenderHot &rv, const float4 *tab
             ORT_PHASE(pr, sv, 7, true);
             if (P.ps == PS_HIT) resolve_hit<COUNTERS, TABS, kLdsStack, kBlock, true>(sv, tab, P.org, P.dir, T.inv_d, lane_id, h, c, pr, lds_stack, spill, tid);
             ORT_PHASE(pr, sv, 0, P.ps == PS_HIT);
-            tracing = produce_ray<COUNTERS, DIFFUSE, TABS, true>(sv, rv, tab, P, h, c, pr, focal_cache, kBlock, spp_u, late_flag);
+            /* near the end of the launch a lane whose job ends draws no new one while the wave still holds parked paths: the
+               next exchange step hands it one of those (endgame branch above), so that the stashes are empty when the job
+               space is */
+            tracing = produce_ray<COUNTERS, DIFFUSE, TABS, true>(sv, rv, tab, P, h, c, pr, focal_cache, kBlock, spp_u, late_flag, early_end && ltop + rtop > 0u);
             if (tracing) {
                 begin_ray<COUNTERS, TABS, kLdsStack, kBlock>(sv, tab, P, T, h, c, pr, lds_stack, spill, tid);
                 if (COUNTERS) c.rays++;
@@ -2310,7 +2314,7 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
         /* ORT_CACHE_RESIDENT, A/B runs: treat the tree as (not) cache-resident */
         const bool cache_resident = kn.cache_resident >= 0 ? kn.cache_resident != 0 : fast_tree_bytes <= (size_t)(16u << 20);
         cache_resident_tree = cache_resident;
-        rv.refill_below = kn.refill_below >= 0 ? kn.refill_below : (cache_resident ? 12 : 32);
+        rv.refill_below = kn.refill_below >= 0 ? kn.refill_below : (cache_resident ? 16 : 32); /* 12 until the block-major issue (round 3: 8-way shard 64.4 -> 63.8 ms) */
         if (rv.refill_below < 1) rv.refill_below = 1;
         if (rv.refill_below > 64) rv.refill_below = 64;
         /* cache-resident trees (bunny room: 6 MB): 8, worth +10 %.  Trees that leave the 8 x 4 MB of L2 (the 1M-triangle
@@ -2395,7 +2399,9 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
             if (rv.inflight_cap < rv.long_min) rv.inflight_cap = rv.long_min;
             if (rv.inflight_cap < 1u) rv.inflight_cap = 1u;
             {
-                const unsigned long long quarter_jobs = kn.endgame_jobs >= 0 ? (unsigned long long)kn.endgame_jobs : 8ull;
+                /* the last FOUR jobs per lane (round 3, whole frame / 2- / 4- / 8-way shard: 0 jobs 431.5 / 224.4 / 122.3 / 71.6 ms, two
+                   426.3 / 219.8 / 117.5 / 66.1, four 426.4 / 218.8 / 116.6 / 64.6) */
+                const unsigned long long quarter_jobs = kn.endgame_jobs >= 0 ? (unsigned long long)kn.endgame_jobs : 16ull;
                 const unsigned long long tail_jobs = quarter_jobs * (unsigned long long)grid * kBlock / 4ull;
                 rv.endgame_from = rv.job_count > tail_jobs ? rv.job_count - tail_jobs : 0ull;
             }

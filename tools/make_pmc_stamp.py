@@ -1,7 +1,7 @@
 """Developer script (runs here, after a gpurun of tools/prof_pmc.sh on the bench workload): turns the PMC summary
 into profiles/r02_pmc_stamp.json, stamped with the hash of the kernel sources it was measured on.  bench.py quotes
 lanes_active / valu_issue_frac / traffic from it only while that hash matches the tree.
-usage: python3 tools/make_pmc_stamp.py gpurun_out/pmc/summary.txt "<workload key>" [profiles/<copy of the summary>]"""
+usage: python3 tools/make_pmc_stamp.py gpurun_out/pmc/summary.txt "<workload key>" [profiles/<copy of the summary>] [profiles/<stamp>.json]"""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -28,5 +28,8 @@ stamp = {
     "counters": vals,
 }
 stamp["git_commit"] = commit
-json.dump(stamp, open(os.path.join(ROOT, "profiles", "r02_pmc_stamp.json"), "w"), indent=1)
+out = sys.argv[4] if len(sys.argv) > 4 else os.path.join(ROOT, "profiles", "r03_pmc_stamp.json")
+# useful vector lane-operations per launch: what bench.py's "valu" roofline divides by the live kernel time
+stamp["useful_lane_ops_per_launch"] = vals["SQ_INSTS_VALU"] * 64.0 * lanes
+json.dump(stamp, open(out, "w"), indent=1)
 print(json.dumps({k: stamp[k] for k in ("kernel_hash", "lanes_active", "valu_issue_frac", "hbm_bytes_per_launch", "l2_hit_rate")}))

@@ -1,0 +1,33 @@
+#!/bin/bash
+# Developer script (GPU box): the measurements that go into profiles/ for round 3 -- tests, parity hunts, N=2 rehearsal from a plain
+# process, scaling proxy, bench lines of all configs, rocprofv3 kernel stats of the bench command, phase shares, PMC passes per workload.
+set -o pipefail
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/r3final
+rm -rf $O; mkdir -p $O
+cd $R
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc $?" >> $O/progress.txt
+STRESS_COUNTERS=0 timeout -k 10 400 python3 tools/stress_parity.py 30 150 > $O/stress_production.log 2>&1; echo "stress production rc $?" >> $O/progress.txt
+STRESS_COUNTERS=0 ORT_EXCHANGE=1 STRESS_SEED0=8100 timeout -k 10 400 python3 tools/stress_parity.py 20 120 > $O/stress_exchange.log 2>&1; echo "stress exchange rc $?" >> $O/progress.txt
+STRESS_COUNTERS=0 ORT_WIDE=1 STRESS_SEED0=8200 timeout -k 10 400 python3 tools/stress_parity.py 20 90 > $O/stress_wide.log 2>&1; echo "stress wide rc $?" >> $O/progress.txt
+STRESS_SEED0=8300 timeout -k 10 400 python3 tools/stress_parity.py 20 90 > $O/stress_counters.log 2>&1; echo "stress counters rc $?" >> $O/progress.txt
+ORT_BENCH_SHARE_GPU=1 timeout -k 10 300 python3 bench.py --gpus 2 --steps 2 --warmup 1 --spp 128 > $O/rehearsal.json 2> $O/rehearsal.err; echo "rehearsal rc $?" >> $O/progress.txt
+PROXY_REPS=3 timeout -k 10 300 python3 tools/scaling_proxy.py c3_bunny_room 1920 1080 1024 64 $O/scaling_proxy.json > $O/scaling_proxy.log 2>&1; echo "proxy rc $?" >> $O/progress.txt
+PROXY_WORLDS=1,8 timeout -k 10 300 python3 tools/scaling_proxy.py c4_dwarf_room 3840 2160 512 64 $O/scaling_proxy_c4.json > $O/scaling_proxy_c4.log 2>&1
+timeout -k 10 400 python3 bench.py --steps 10 --warmup 3 > $O/bench.json 2> $O/bench.err; echo "bench rc $?" >> $O/progress.txt
+(cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err)
+find $O/stats -name "*kernel_stats.csv" -exec cp {} $O/bench_kernel_stats.csv \;
+rm -rf $O/stats
+echo "stats done" >> $O/progress.txt
+timeout -k 10 300 python3 bench.py --scene c2_analytic --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_c2.json 2> $O/bench_c2.err
+timeout -k 10 300 python3 bench.py --scene c4_dwarf_room --width 3840 --height 2160 --spp 512 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_c4.json 2> $O/bench_c4.err
+timeout -k 10 300 python3 bench.py --scene c5_heightfield_708 --width 3840 --height 2160 --spp 256 --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_c5.json 2> $O/bench_c5.err
+timeout -k 10 300 python3 bench.py --policy tile32 --spp 64 --steps 1 --warmup 1 --no-cpu-baseline > $O/bench_tile32.json 2> $O/bench_tile32.err
+echo "benches done" >> $O/progress.txt
+timeout -k 10 300 python3 tools/util_run.py c3_bunny_room 1920 1080 1024 64 > $O/util_c3_exchange.log 2>&1
+ORT_EXCHANGE=0 timeout -k 10 300 python3 tools/util_run.py c3_bunny_room 1920 1080 1024 64 > $O/util_c3_plain.log 2>&1
+timeout -k 10 300 python3 tools/util_run.py c2_analytic 1920 1080 1024 64 > $O/util_c2.log 2>&1
+echo "util done" >> $O/progress.txt
+bash tools/r3_stamps.sh > $O/stamps.log 2>&1; cp -r gpurun_out/stamps $O/stamps; echo "stamps done" >> $O/progress.txt
+tail -3 $O/pytest.log | head -1; cat $O/progress.txt; tail -2 $O/stress_*.log; grep "^N=" $O/scaling_proxy.log $O/scaling_proxy_c4.log
+for f in $O/bench.json $O/bench_c*.json $O/bench_tile32.json $O/rehearsal.json; do python3 -c "import json,sys; d=json.load(open('$f')); print('$f', round(d['value'],1), round(d['roofline']['kernel_ms'],2), d['roofline']['bound'], round(d['roofline']['frac'],3))"; done
