@@ -173,8 +173,12 @@ def cpu_baseline(args, scene_path):
         x0, x1, y0, y1, spp = W // 2 - 64, W // 2 + 64, H // 2 - 32, H // 2 + 32, 2
         sample = "central %dx%d px of the %dx%d frame, %d spp, per-pixel seeds" % (x1 - x0, y1 - y0, W, H, spp)
     _, st = osc.render(W, H, spp, args.seed, "pixel", rect=(x0, y0, x1, y1), threads=cores)
+    note = ("the reference build cannot hold this mesh (its fixed arenas overflow): the oracle walks the reference's octree instead"
+            if args.scene.startswith("c5_heightfield_") else
+            "oracle/_ref/ref_glibc (the reference's own sources compiled by `make -C oracle ref`, git-ignored, needs /root/reference) is "
+            "absent on this machine: timed the plain-C restatement instead")
     return {"value": st["paths"] / st["seconds"] / 1e6, "unit": "Mpaths/s", "cores": cores, "kind": "port",
-            "sample": sample + "; oracle/liboracle.so (plain-C restatement), pthreads"}
+            "sample": sample + "; oracle/liboracle.so (plain-C restatement), pthreads", "note": note}
 
 
 def kernel_source_hash():

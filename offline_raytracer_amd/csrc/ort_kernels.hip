@@ -214,7 +214,7 @@ struct Knobs {
     int exchange = -1;         /* ORT_EXCHANGE */
     int long_min = -1, long_refill = -1, inflight_cap = -1, park_min = -1; /* ORT_LONG_MIN, ORT_LONG_REFILL, ORT_INFLIGHT_CAP, ORT_PARK_MIN */
     int lpt = -1;              /* ORT_LPT=0: CHUNK jobs issued chunk-major (rounds 1-2) instead of block-major */
-    int wide = -1;             /* ORT_WIDE: 4-wide tree (default: for trees that leave the L2) */
+    int wide = -1;             /* ORT_WIDE=1: traverse the 4-wide form of the tree (default: never) */
     int endgame_jobs = -1;     /* ORT_ENDGAME_JOBS: the ray exchange drains its stashes over the last n/4 jobs per lane (default 16 = four jobs) */
     int blocks_per_cu = -1;    /* ORT_BLOCKS_PER_CU (takes effect at upload) */
 };
@@ -2306,14 +2306,12 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
     rv.x0 = p->x0; rv.y0 = p->y0; rv.x1 = p->x1; rv.y1 = p->y1;
     rv.seed = p->seed; rv.spp = p->spp; rv.chunk = p->chunk; rv.rr = p->rr;
     rv.out = out;
-    bool cache_resident_tree = true;
     {
         /* tuning knobs; results do not depend on them.  Defaults tuned on MI355X (profiles/r01_tuning.md)
            separately for trees that stay in L2 and trees that do not */
         const size_t fast_tree_bytes = scene->tree.nodes.size() * sizeof(DevNode) + scene->tree.tris.size() * sizeof(DevTri);
         /* ORT_CACHE_RESIDENT, A/B runs: treat the tree as (not) cache-resident */
         const bool cache_resident = kn.cache_resident >= 0 ? kn.cache_resident != 0 : fast_tree_bytes <= (size_t)(16u << 20);
-        cache_resident_tree = cache_resident;
         rv.refill_below = kn.refill_below >= 0 ? kn.refill_below : (cache_resident ? 16 : 32); /* 12 until the block-major issue (round 3: 8-way shard 64.4 -> 63.8 ms) */
         if (rv.refill_below < 1) rv.refill_below = 1;
         if (rv.refill_below > 64) rv.refill_below = 64;
@@ -2381,8 +2379,9 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
            what it has parked, which short launches and 4- or 8-way shards cannot amortise (round 3, with the sorted issue of
            the job space: a 4-way shard of the headline frame, 32 jobs per lane, 120.8 ms plain / 122.5 with the exchange; a
            2-way shard, 63 per lane, 232.8 / 225.6).  ORT_EXCHANGE=0 / 1 forces it. */
-        /* ... and not for trees that leave the L2 (the 1M-triangle scene: 1 268 with it, 1 272 without) */
-        const bool worth_it = diffuse && cache_resident_tree && rv.job_count >= 48ull * (unsigned long long)grid * kBlock;
+        /* (trees that leave the L2 included since the stashes are drained before the end of the launch: the 1M-triangle scene
+           1 405 Mpaths/s with it, 1 351 without; round 2: 1 268 / 1 272) */
+        const bool worth_it = diffuse && rv.job_count >= 48ull * (unsigned long long)grid * kBlock;
         exch = tabs && rv.mode != JOBS_EXPLICIT && (kn.exchange >= 0 ? kn.exchange != 0 : worth_it) && (!counters || (want_util && diffuse));
         if (exch && kn.refill_below < 0) rv.refill_below = 16; /* stragglers park instead of idling: leave the loop a little earlier */
         if (exch) {
@@ -2433,11 +2432,10 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
         if (rc) return rc;
     } else {
 #define ORT_LAUNCH(C, D, T) hipLaunchKernelGGL((pt_persistent<C, D, T>), dim3(grid), dim3(kBlock), 0, stream, sv, hot)
-        /* 4-wide tree (DevNode4): half the dependent node fetches per ray, for trees that leave the L2 (the 1M-triangle
-           scene); the cache-resident scenes make ~1.5 node visits per ray after the prologue and keep the leaner binary
-           variants.  ORT_WIDE=0 / 1 forces it (same image either way). */
-        const bool wide = d->nodes4 && !exch && tabs && (counters || rv.mode != JOBS_EXPLICIT) && !(counters && diffuse && want_util) &&
-                          (kn.wide >= 0 ? kn.wide != 0 : !cache_resident_tree);
+        /* 4-wide tree (DevNode4): half the dependent node fetches per ray -- and twice the vector instructions per visit, in a
+           kernel that is issue-bound at a third of its lanes on the trees it was meant for: 1 218 against 1 368 Mpaths/s on the
+           1M-triangle scene (profiles/r03_tuning.md).  Off unless ORT_WIDE=1 asks for it (same image either way). */
+        const bool wide = d->nodes4 && !exch && tabs && (counters || rv.mode != JOBS_EXPLICIT) && !(counters && diffuse && want_util) && kn.wide > 0;
         if (wide) {
             sv.nodes = (const float4 *)d->nodes4;
             if (counters) hipLaunchKernelGGL((pt_persistent<true, false, true, false, true>), dim3(grid), dim3(kBlock), 0, stream, sv, hot);
