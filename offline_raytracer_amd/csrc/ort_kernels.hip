@@ -26,8 +26,23 @@
 #include "ort_device.h"
 #include "ort_scene.h"
 
-namespace ort {
+/* This file is compiled twice (ort_kernels_w5.hip includes it with ORT_W5_TU defined): the library's kernels at four waves per
+   SIMD, and the two plain-loop kernels that run better at FIVE (96 registers, 20 LDS stack entries, built with machine LICM off)
+   in a translation unit and a namespace of their own -- same lane code, other limits; the host side exists once. */
+#ifdef ORT_W5_TU
+#define ORT_NS ort_w5
+#else
+#define ORT_NS ort
+#if !defined(ORT_HOST_SIM)
+void ort_launch_w5(int diffuse, unsigned int grid, void *stream, const void *sv_bytes, const void *hot_bytes); /* ort_kernels_w5.hip */
+size_t ort_w5_sizeof_scene_view();
+size_t ort_w5_sizeof_render_hot();
+#endif
+#endif
 
+namespace ORT_NS {
+
+using namespace ort;
 using namespace ortd;
 
 constexpr int kBlock = 256;      /* 4 waves */
@@ -215,6 +230,7 @@ struct Knobs {
     int long_min = -1, long_refill = -1, inflight_cap = -1, park_min = -1; /* ORT_LONG_MIN, ORT_LONG_REFILL, ORT_INFLIGHT_CAP, ORT_PARK_MIN */
     int lpt = -1;              /* ORT_LPT=0: CHUNK jobs issued chunk-major (rounds 1-2) instead of block-major */
     int wide = -1;             /* ORT_WIDE=1: traverse the 4-wide form of the tree (default: never) */
+    int waves5 = -1;           /* ORT_WAVES5=0 / 1: the plain loop's five-waves-per-SIMD build (default: all-lobes flavour, trees that leave the L2) */
     int endgame_jobs = -1;     /* ORT_ENDGAME_JOBS: the ray exchange drains its stashes over the last n/4 jobs per lane (default 16 = four jobs) */
     int blocks_per_cu = -1;    /* ORT_BLOCKS_PER_CU (takes effect at upload) */
 };
@@ -242,6 +258,7 @@ static Knobs read_knobs() {
     k.park_min = env_int("ORT_PARK_MIN");
     k.lpt = env_int("ORT_LPT");
     k.wide = env_int("ORT_WIDE");
+    k.waves5 = env_int("ORT_WAVES5");
     k.endgame_jobs = env_int("ORT_ENDGAME_JOBS");
     k.blocks_per_cu = env_int("ORT_BLOCKS_PER_CU");
     return k;
@@ -1558,6 +1575,10 @@ ORT_D uint32_t lane_rank(unsigned long long mask) { /* set bits of mask below th
 }
 
 constexpr uint32_t kStashVecs = 9u; /* float4 per parked path */
+#ifndef ORT_STASH_CONST
+#define ORT_STASH_CONST 1 /* 1: the stash capacities are compile-time constants, so the nine plane offsets of a record are literals instead of scalar registers (which were spilled) */
+#endif
+constexpr uint32_t kCapL = 128u, kCapR = 192u; /* parked paths per wave: unfinished rays / finished rays */
 static_assert(kLdsStack % 4 == 0, "the L stash carves its stack words out of float4 units (kLdsStack / 4 per parked path)");
 ORT_D void stash_store(const Stash &st, uint32_t slot, const PathState &P, const HitState &h, uint32_t cur, int sp, V3 inv_d, const float *focal_cache,
                        uint32_t info_chain = 0u, uint32_t info_mat = 0u) {
@@ -1613,9 +1634,15 @@ ORT_D void pt_lane_x(const SceneView &sv, const RenderHot &rv, const float4 *tab
     const uint32_t spp_u = (rv.mode == JOBS_PIXEL) ? rv.c->spp : rv.c->chunk;                /* samples per (one-pixel) job */
     float4 *wbase = rv.c->stash + (size_t)wave * rv.c->stash_wave_f4;
     Stash L, R;
+#if ORT_STASH_CONST
+    L.rec = wbase; L.cap = kCapL;
+    L.stk = (uint32_t *)(wbase + kStashVecs * kCapL);
+    R.rec = wbase + (kStashVecs + (uint32_t)kLdsStack / 4u) * kCapL; R.cap = kCapR; R.stk = nullptr;
+#else
     L.rec = wbase; L.cap = rv.c->capL;
     L.stk = (uint32_t *)(wbase + kStashVecs * rv.c->capL);
     R.rec = wbase + (kStashVecs + (uint32_t)kLdsStack / 4u) * rv.c->capL; R.cap = rv.c->capR; R.stk = nullptr;
+#endif
     uint32_t ltop = 0, rtop = 0; /* wave-uniform */
     float *focal_cache = lds_focal + tid;
     /* the wave stops parking, and hands its parked paths to free lanes before new jobs, as soon as one of its lanes has
@@ -1880,6 +1907,22 @@ pt_persistent_x(SceneView sv, RenderHot rv) {
     }
 }
 
+#ifdef ORT_W5_TU
+} // namespace ort_w5
+/* the five-waves variants of the plain loop, launched by device_render (ort_kernels.hip proper).  The argument structs are
+   the same declarations compiled in this unit's namespace: passed as bytes */
+void ort_launch_w5(int diffuse, unsigned int grid, void *stream, const void *sv_bytes, const void *hot_bytes) {
+    ort_w5::SceneView sv;
+    ort_w5::RenderHot hot;
+    memcpy(&sv, sv_bytes, sizeof(sv));
+    memcpy(&hot, hot_bytes, sizeof(hot));
+    if (diffuse) hipLaunchKernelGGL((ort_w5::pt_persistent<false, true, true, true>), dim3(grid), dim3(ort_w5::kBlock), 0, (hipStream_t)stream, sv, hot);
+    else hipLaunchKernelGGL((ort_w5::pt_persistent<false, false, true, true>), dim3(grid), dim3(ort_w5::kBlock), 0, (hipStream_t)stream, sv, hot);
+}
+size_t ort_w5_sizeof_scene_view() { return sizeof(ort_w5::SceneView); }
+size_t ort_w5_sizeof_render_hot() { return sizeof(ort_w5::RenderHot); }
+namespace ort_w5 {
+#else
 /* wavefront kernels: fixed-size grids, grid-stride over the slots */
 template <bool COUNTERS>
 __global__ void __launch_bounds__(kBlock) wf_shade(SceneView sv, RenderHot rv, WfView wf, int count_active) {
@@ -2306,12 +2349,14 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
     rv.x0 = p->x0; rv.y0 = p->y0; rv.x1 = p->x1; rv.y1 = p->y1;
     rv.seed = p->seed; rv.spp = p->spp; rv.chunk = p->chunk; rv.rr = p->rr;
     rv.out = out;
+    bool cache_resident_tree = true;
     {
         /* tuning knobs; results do not depend on them.  Defaults tuned on MI355X (profiles/r01_tuning.md)
            separately for trees that stay in L2 and trees that do not */
         const size_t fast_tree_bytes = scene->tree.nodes.size() * sizeof(DevNode) + scene->tree.tris.size() * sizeof(DevTri);
         /* ORT_CACHE_RESIDENT, A/B runs: treat the tree as (not) cache-resident */
         const bool cache_resident = kn.cache_resident >= 0 ? kn.cache_resident != 0 : fast_tree_bytes <= (size_t)(16u << 20);
+        cache_resident_tree = cache_resident;
         rv.refill_below = kn.refill_below >= 0 ? kn.refill_below : (cache_resident ? 16 : 32); /* 12 until the block-major issue (round 3: 8-way shard 64.4 -> 63.8 ms) */
         if (rv.refill_below < 1) rv.refill_below = 1;
         if (rv.refill_below > 64) rv.refill_below = 64;
@@ -2359,17 +2404,23 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
 
     const bool counters = (p->flags & ORT_RENDER_COUNTERS) != 0;
     ORT_HIP(hipMemsetAsync(d->ctrl, 0, 128 * sizeof(unsigned long long), stream));
-    /* persistent grid: 4 blocks of 256 lanes per CU, never more lanes than jobs */
-    unsigned long long lanes_wanted = rv.job_count;
-    unsigned int max_blocks = d->max_blocks;
-    unsigned int grid = (unsigned int)((lanes_wanted + kBlock - 1) / kBlock);
-    if (grid > max_blocks) grid = max_blocks;
-    if (grid == 0) grid = 1;
     const bool wavefront = kn.wavefront; /* ORT_MODE=wavefront; results are identical */
     const bool diffuse = d->diffuse_only && !kn.general_kernel; /* ORT_KERNEL=general forces the all-lobes kernel (A/B runs; same results) */
     /* TABS: the scene's small tables all fit their LDS slots (every scene of this repository); otherwise HBM */
     const uint32_t all_tabs = TAB_PRO | TAB_LIGHTS | TAB_MATS;
     const bool tabs = (d->tab_flags & all_tabs) == all_tabs && kn.lds_tables != 0; /* ORT_LDS_TABLES=0: read them from HBM anyway (A/B runs; same results) */
+    /* the plain loop of implicit job spaces runs at FIVE waves per SIMD (ort_kernels_w5.hip: 96 registers, 20 LDS stack entries,
+       machine LICM off): same call, four / five waves: analytic scene 3 302 / 3 514 Mpaths/s, glass room 3 625 / 3 848, testscene
+       2 790 / 2 885, 1M-triangle scene 1 401 / 1 500, dwarf room (exchange off) 3 929 / 4 088, bunny room (exchange off) 4 729 / 4 712;
+       the ray exchange stays at four (bunny room 5 053 / 4 949).  ORT_WAVES5=0 / 1 forces. */
+    const bool can_five = !wavefront && !counters && tabs && rv.mode != JOBS_EXPLICIT && kn.wide <= 0 && kn.exchange <= 0 &&
+                          ort_w5_sizeof_scene_view() == sizeof(SceneView) && ort_w5_sizeof_render_hot() == sizeof(RenderHot);
+    /* persistent grid: 4 blocks of 256 lanes per CU (5 for the five-waves kernels, decided below), never more lanes than jobs */
+    unsigned long long lanes_wanted = rv.job_count;
+    unsigned int max_blocks = d->max_blocks;
+    unsigned int grid = (unsigned int)((lanes_wanted + kBlock - 1) / kBlock);
+    if (grid > max_blocks) grid = max_blocks;
+    if (grid == 0) grid = 1;
     bool exch = false;
     if (!wavefront) {
         /* ray exchange (pt_lane_x): bit-identical; 60 of 64 lanes in the shading pass instead of 53 and leaf
@@ -2379,13 +2430,13 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
            what it has parked, which short launches and 4- or 8-way shards cannot amortise (round 3, with the sorted issue of
            the job space: a 4-way shard of the headline frame, 32 jobs per lane, 120.8 ms plain / 122.5 with the exchange; a
            2-way shard, 63 per lane, 232.8 / 225.6).  ORT_EXCHANGE=0 / 1 forces it. */
-        /* (trees that leave the L2 included since the stashes are drained before the end of the launch: the 1M-triangle scene
-           1 405 Mpaths/s with it, 1 351 without; round 2: 1 268 / 1 272) */
-        const bool worth_it = diffuse && rv.job_count >= 48ull * (unsigned long long)grid * kBlock;
+        /* ... and not for trees that leave the L2: the 1M-triangle scene runs 1 392 Mpaths/s with it and 1 393 without (round 2:
+           1 268 / 1 272), and its stashes would move 3 TB/s through the fabric for that */
+        const bool worth_it = diffuse && cache_resident_tree && rv.job_count >= 48ull * (unsigned long long)grid * kBlock;
         exch = tabs && rv.mode != JOBS_EXPLICIT && (kn.exchange >= 0 ? kn.exchange != 0 : worth_it) && (!counters || (want_util && diffuse));
         if (exch && kn.refill_below < 0) rv.refill_below = 16; /* stragglers park instead of idling: leave the loop a little earlier */
         if (exch) {
-            rv.capL = 128; rv.capR = 192;
+            rv.capL = kCapL; rv.capR = kCapR;
             rv.long_min = kn.long_min >= 0 ? (uint32_t)kn.long_min : 64u;
             rv.long_refill = kn.long_refill >= 0 ? (uint32_t)kn.long_refill : 32u;
             rv.inflight_cap = kn.inflight_cap >= 0 ? (uint32_t)kn.inflight_cap : 64u;
@@ -2410,11 +2461,18 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
             rv.stash = (float4 *)d->stash;
         }
     }
+    const bool five = can_five && !exch && (kn.waves5 >= 0 ? kn.waves5 != 0 : true);
+    if (five && kn.blocks_per_cu <= 0) {
+        max_blocks = (unsigned int)(d->cu_count > 0 ? d->cu_count : 256) * 5u;
+        grid = (unsigned int)((lanes_wanted + kBlock - 1) / kBlock);
+        if (grid > max_blocks) grid = max_blocks;
+        if (grid == 0) grid = 1;
+    }
     /* CHUNK renders issue their jobs block-major (see "the order in which a CHUNK render issues its jobs"); ORT_LPT=0:
        chunk-major as in rounds 1-2 (A/B runs; same image either way) */
     if (rv.mode == JOBS_CHUNK && rv.nchunks >= 2u && kn.lpt != 0) rv.block_major = 1u;
     if (kn.debug_drain && stats && !wavefront) {
-        const size_t bytes = (size_t)d->max_blocks * (kBlock / 64) * sizeof(unsigned long long);
+        const size_t bytes = (size_t)max_blocks * (kBlock / 64) * sizeof(unsigned long long);
         if ((rc = ensure(&d->drain, &d->drain_bytes, bytes, err))) return rc;
         ORT_HIP(hipMemsetAsync(d->drain, 0, bytes, stream));
         rv.drain = (unsigned long long *)d->drain;
@@ -2436,6 +2494,9 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
            kernel that is issue-bound at a third of its lanes on the trees it was meant for: 1 218 against 1 368 Mpaths/s on the
            1M-triangle scene (profiles/r03_tuning.md).  Off unless ORT_WIDE=1 asks for it (same image either way). */
         const bool wide = d->nodes4 && !exch && tabs && (counters || rv.mode != JOBS_EXPLICIT) && !(counters && diffuse && want_util) && kn.wide > 0;
+        if (five && !exch) {
+            ort_launch_w5(diffuse ? 1 : 0, grid, (void *)stream, &sv, &hot);
+        } else
         if (wide) {
             sv.nodes = (const float4 *)d->nodes4;
             if (counters) hipLaunchKernelGGL((pt_persistent<true, false, true, false, true>), dim3(grid), dim3(kBlock), 0, stream, sv, hot);
@@ -2538,6 +2599,7 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
     return ORT_OK;
 }
 
+#endif /* !ORT_W5_TU */
 #endif /* !ORT_HOST_SIM */
 
-} // namespace ort
+} // namespace ORT_NS

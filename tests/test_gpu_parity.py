@@ -231,6 +231,31 @@ def test_wide_tree_equals_binary_tree(api, oracle, gpu_scene, monkeypatch, name,
     assert_bits_equal(b, ref, "wide tree vs oracle")
 
 
+@pytest.mark.parametrize("name,w,h,spp,chunk", [("c2_analytic", 200, 120, 16, 4), ("c3_bunny_room", 256, 144, 16, 4), ("c5_heightfield_224", 256, 144, 8, 4),
+                                                  ("glass_room", 160, 90, 16, 4)])
+def test_five_waves_build_equals_four_waves_build(api, oracle, gpu_scene, monkeypatch, name, w, h, spp, chunk):
+    """the plain loop exists twice: at four waves per SIMD (128 registers, 24 LDS stack entries) and at five (96 registers, 20
+    entries, ort_kernels_w5.hip -- chosen by itself for the all-lobes flavour and for trees that leave the L2).  Same lane code:
+    same bits, CHUNK and PIXEL policies, also with every 16th ray re-cast exactly (resolve_hit's re-traversals use the shorter
+    LDS stack), and equal to the oracle"""
+    scene = gpu_scene(name)
+    monkeypatch.setenv("ORT_EXCHANGE", "0")
+    monkeypatch.setenv("ORT_WAVES5", "0")
+    a, _ = scene.render(w, h, spp, 29, "chunk", chunk=chunk)
+    ap, _ = scene.render(w, h, spp, 29, "pixel")
+    monkeypatch.setenv("ORT_WAVES5", "1")
+    b, _ = scene.render(w, h, spp, 29, "chunk", chunk=chunk)
+    bp, _ = scene.render(w, h, spp, 29, "pixel")
+    assert_bits_equal(a, b, "five waves vs four, CHUNK")
+    assert_bits_equal(ap, bp, "five waves vs four, PIXEL")
+    monkeypatch.setenv("ORT_DEBUG_FORCE_FALLBACK", "0xf")
+    c, _ = scene.render(w, h, spp, 29, "chunk", chunk=chunk)
+    assert_bits_equal(a, c, "five waves with forced exact re-casts")
+    monkeypatch.delenv("ORT_DEBUG_FORCE_FALLBACK")
+    ref, _ = oracle.OracleScene(scene.flatten(w, h)).render(w, h, spp, 29, "chunk", chunk=chunk, threads=16)
+    assert_bits_equal(b, ref, "five waves vs oracle")
+
+
 def test_issue_order_of_chunk_jobs_does_not_matter(api, gpu_scene, monkeypatch):
     """CHUNK renders issue their jobs block-major -- [block][chunk][pixel]: all chunks of an 8x8 block together
     (ort_kernels.hip, "the order in which a CHUNK render issues its jobs") -- instead of chunk-major as in rounds 1-2
