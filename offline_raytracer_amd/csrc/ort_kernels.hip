@@ -2409,10 +2409,12 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
     /* TABS: the scene's small tables all fit their LDS slots (every scene of this repository); otherwise HBM */
     const uint32_t all_tabs = TAB_PRO | TAB_LIGHTS | TAB_MATS;
     const bool tabs = (d->tab_flags & all_tabs) == all_tabs && kn.lds_tables != 0; /* ORT_LDS_TABLES=0: read them from HBM anyway (A/B runs; same results) */
-    /* the plain loop of implicit job spaces runs at FIVE waves per SIMD (ort_kernels_w5.hip: 96 registers, 20 LDS stack entries,
-       machine LICM off): same call, four / five waves: analytic scene 3 302 / 3 514 Mpaths/s, glass room 3 625 / 3 848, testscene
-       2 790 / 2 885, 1M-triangle scene 1 401 / 1 500, dwarf room (exchange off) 3 929 / 4 088, bunny room (exchange off) 4 729 / 4 712;
-       the ray exchange stays at four (bunny room 5 053 / 4 949).  ORT_WAVES5=0 / 1 forces. */
+    /* the plain loop of implicit job spaces exists at FIVE waves per SIMD as well (ort_kernels_w5.hip: 96 registers, 20 LDS stack
+       entries, machine LICM off).  Same call, four / five waves: analytic scene 3 302 / 3 514 Mpaths/s, glass room 3 625 / 3 848,
+       testscene 2 790 / 2 885, 1M-triangle scene 1 401 / 1 500 -- the all-lobes flavour and trees that leave the L2 take it.  The
+       diffuse flavour on a cache-resident tree does not: bunny room whole frame 4 729 / 4 712, its 4- / 8-way shards 117.0 / 119.2 and
+       63.5 / 65.9 ms (a quarter more lanes, a quarter fewer jobs per lane: the tail weighs more); nor the ray exchange (5 053 / 4 949).
+       ORT_WAVES5=0 / 1 forces. */
     const bool can_five = !wavefront && !counters && tabs && rv.mode != JOBS_EXPLICIT && kn.wide <= 0 && kn.exchange <= 0 &&
                           ort_w5_sizeof_scene_view() == sizeof(SceneView) && ort_w5_sizeof_render_hot() == sizeof(RenderHot);
     /* persistent grid: 4 blocks of 256 lanes per CU (5 for the five-waves kernels, decided below), never more lanes than jobs */
@@ -2426,13 +2428,13 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
         /* ray exchange (pt_lane_x): bit-identical; 60 of 64 lanes in the shading pass instead of 53 and leaf
            visits four times better filled, against the parking traffic.  On by itself where it is a gain
            (profiles/r02_tuning.md): the diffuse flavour (the all-lobes one spills too much around the exchange) on
-           launches of at least 48 jobs per lane -- every parked path is a job in progress, so a wave's tail grows with
-           what it has parked, which short launches and 4- or 8-way shards cannot amortise (round 3, with the sorted issue of
-           the job space: a 4-way shard of the headline frame, 32 jobs per lane, 120.8 ms plain / 122.5 with the exchange; a
-           2-way shard, 63 per lane, 232.8 / 225.6).  ORT_EXCHANGE=0 / 1 forces it. */
+           launches of at least 24 jobs per lane -- every parked path is a job in progress, so a wave's tail grows with
+           what it has parked, which short launches cannot amortise (round 3, stashes drained over the last four jobs per
+           lane: 2- / 4- / 8-way shard of the headline frame, 63 / 32 / 16 jobs per lane: 216.2 / 115.5 / 65.2 ms with the exchange,
+           228.6 / 117.0 / 63.5 plain).  ORT_EXCHANGE=0 / 1 forces it. */
         /* ... and not for trees that leave the L2: the 1M-triangle scene runs 1 392 Mpaths/s with it and 1 393 without (round 2:
            1 268 / 1 272), and its stashes would move 3 TB/s through the fabric for that */
-        const bool worth_it = diffuse && cache_resident_tree && rv.job_count >= 48ull * (unsigned long long)grid * kBlock;
+        const bool worth_it = diffuse && cache_resident_tree && rv.job_count >= 24ull * (unsigned long long)grid * kBlock;
         exch = tabs && rv.mode != JOBS_EXPLICIT && (kn.exchange >= 0 ? kn.exchange != 0 : worth_it) && (!counters || (want_util && diffuse));
         if (exch && kn.refill_below < 0) rv.refill_below = 16; /* stragglers park instead of idling: leave the loop a little earlier */
         if (exch) {
@@ -2461,7 +2463,7 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
             rv.stash = (float4 *)d->stash;
         }
     }
-    const bool five = can_five && !exch && (kn.waves5 >= 0 ? kn.waves5 != 0 : true);
+    const bool five = can_five && !exch && (kn.waves5 >= 0 ? kn.waves5 != 0 : (!diffuse || !cache_resident_tree));
     if (five && kn.blocks_per_cu <= 0) {
         max_blocks = (unsigned int)(d->cu_count > 0 ? d->cu_count : 256) * 5u;
         grid = (unsigned int)((lanes_wanted + kBlock - 1) / kBlock);

@@ -7,11 +7,11 @@
  * binary64 constants of the libm polynomials and the stash / table addresses are held in registers across everything and
  * spilled (all-lobes flavour at 96 registers: 90 spilled vector registers and 206 spilled scalar ones with it, 60 and 49 without).
  * Why (profiles/r03_tuning.md): the kernel is bound by memory latency and instruction issue, and a fifth wave per SIMD hides more
- * of both than the spills cost -- in the plain loop: analytic scene 3 302 -> 3 514 Mpaths/s, glass room 3 625 -> 3 848, 1M-triangle
- * scene 1 401 -> 1 500, dwarf room with the exchange off 3 929 -> 4 088; three waves lose 13-15 %, six lose again (161-190 spilled
- * registers), and the ray exchange is better off at four (bunny room 5 053 -> 4 949), so it stays in ort_kernels.hip proper.
- * device_render chooses (every plain-loop launch of an implicit job space); ORT_WAVES5=0 / 1 forces.  Same lane code, same results
- * (tests/test_gpu_parity.py::test_five_waves_build_equals_four_waves_build).
+ * of both than the spills cost -- for the all-lobes flavour (analytic scene 3 302 -> 3 514 Mpaths/s, glass room 3 625 -> 3 848) and
+ * for trees that leave the L2 (1M-triangle scene 1 401 -> 1 500); three waves lose 13-15 %, six lose again (161-190 spilled
+ * registers).  The diffuse flavour on cache-resident trees gains nothing (and its small shards lose: more lanes, fewer jobs per
+ * lane), the ray exchange loses 2 %: those stay at four waves, in ort_kernels.hip proper.  device_render chooses; ORT_WAVES5=0 / 1
+ * forces.  Same lane code, same results (tests/test_gpu_parity.py::test_five_waves_build_equals_four_waves_build).
  */
 #define ORT_W5_TU 1
 #define ORT_WAVES_PER_EU 5

@@ -40,7 +40,7 @@ def test_full_frame_determinism_and_shards(api, gpu_scene):
 
 def test_full_frame_ray_exchange(api, gpu_scene, monkeypatch):
     """the whole 1920x1080 frame (2 M pixels, 32 spp in 8-sample jobs = 32 jobs per lane): exchange forced off == forced on
-    == left to itself (on from 48 jobs per lane), bit for bit"""
+    == left to itself (on from 24 jobs per lane), bit for bit"""
     scene = gpu_scene("c3_bunny_room")
     spp, chunk, seed = 32, 8, 2025
     monkeypatch.setenv("ORT_EXCHANGE", "0")
