@@ -186,7 +186,7 @@ def kernel_source_hash():
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "offline_raytracer_amd", "csrc")
-    for name in ("ort_kernels.hip", "ort_kernels_w5.hip", "ort_device.h", "ort_detmath.h", "ort_scene.h"):
+    for name in ("ort_lane.h", "ort_kernels.hip", "ort_kernels_w5.hip", "ort_device.h", "ort_detmath.h", "ort_scene.h"):
         with open(os.path.join(d, name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]

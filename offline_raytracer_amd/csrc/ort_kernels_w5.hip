@@ -1,7 +1,7 @@
 /*
  * ort_kernels_w5.hip -- the plain-loop path-trace kernels at FIVE waves per SIMD.
  *
- * The lane code is ort_kernels.hip's, compiled a second time with other limits: 96 vector registers per lane instead of 128
+ * The lane code (ort_lane.h) compiled a second time, with other limits: 96 vector registers per lane instead of 128
  * (5 waves per SIMD instead of 4), 20 LDS traversal-stack entries per lane instead of 24 (five workgroups' LDS must fit one CU:
  * 5 x 30.4 KB), and -- the Makefile's doing -- with LLVM's machine LICM switched off: hoisted out of the one big lane loop, the
  * binary64 constants of the libm polynomials and the stash / table addresses are held in registers across everything and
@@ -17,4 +17,17 @@
 #define ORT_WAVES_PER_EU 5
 #define ORT_LDS_STACK 20
 #define ORT_SPILL_STACK 44
-#include "ort_kernels.hip"
+#include "ort_lane.h"
+
+/* the five-waves variants of the plain loop, launched by device_render (ort_kernels.hip proper).  The argument structs are
+   the same declarations compiled in this unit's namespace: passed as bytes */
+void ort_launch_w5(int diffuse, unsigned int grid, void *stream, const void *sv_bytes, const void *hot_bytes) {
+    ort_w5::SceneView sv;
+    ort_w5::RenderHot hot;
+    memcpy(&sv, sv_bytes, sizeof(sv));
+    memcpy(&hot, hot_bytes, sizeof(hot));
+    if (diffuse) hipLaunchKernelGGL((ort_w5::pt_persistent<false, true, true, true>), dim3(grid), dim3(ort_w5::kBlock), 0, (hipStream_t)stream, sv, hot);
+    else hipLaunchKernelGGL((ort_w5::pt_persistent<false, false, true, true>), dim3(grid), dim3(ort_w5::kBlock), 0, (hipStream_t)stream, sv, hot);
+}
+size_t ort_w5_sizeof_scene_view() { return sizeof(ort_w5::SceneView); }
+size_t ort_w5_sizeof_render_hot() { return sizeof(ort_w5::RenderHot); }

@@ -44,7 +44,7 @@ constexpr uint32_t NODE_INDEX_MASK = 0x3fffffffu;
 constexpr uint32_t EMPTY_CHILD = 0xffffffffu; /* leaf, kind 7: never visited (box is inverted) */
 constexpr uint32_t MAX_LEAF_PRIMS = 16;
 /* depth of the fast tree = what a traversal stack must hold at most.  ONE constant: ort_tree.cpp builds within it
-   (and refuses a tree that exceeds it), ort_kernels.hip static_asserts that its smallest stack (the re-traversal of
+   (and refuses a tree that exceeds it), ort_lane.h static_asserts that its smallest stack (the re-traversal of
    resolve_hit: LDS entries minus the four it borrows, plus the scratch tail) holds it */
 constexpr uint32_t kTreeDepthBudget = 60;
 #ifndef ORT_TREELET_NODES
@@ -113,7 +113,7 @@ struct Tree {
     uint32_t leaf_count = 0, max_leaf_prims = 0, max_depth = 0;
     float sah_cost = 0;
     /* the scene's few analytic shapes are not in the tree: every ray tests all of them up front, the
-       whole wave in step (ort_kernels.hip: start_ray); the tree then holds the triangles only */
+       whole wave in step (ort_lane.h: prologue_tests); the tree then holds the triangles only */
     bool analytic_prologue = false;
     uint32_t pro_boxes = 0, pro_spheres = 0, pro_cyls = 0; /* shapes [0, n) of each kind form the prologue */
     bool built = false;

@@ -317,7 +317,7 @@ DevMaterial make_dev_material(const ort_material &m) {
 void cylinder_frame_for(const ort_cylinder &c, float rot[9], float *len) { cylinder_frame(c, rot, len); }
 
 /* The first kTreeletNodes interior nodes in breadth-first order get the indices [0, kTreeletNodes): the kernel keeps
-   that top of the tree in LDS (ort_kernels.hip, kTabTreelet), where most node visits happen.  Pure renumbering. */
+   that top of the tree in LDS (ort_lane.h, kTabTreelet), where most node visits happen.  Pure renumbering. */
 static void renumber_top_levels(Tree *tree, uint32_t top) {
     const size_t n = tree->nodes.size();
     if (n <= 2) return;
@@ -555,7 +555,7 @@ int build_tree(Scene *scene, std::string *err) {
            they stay out of the tree and form the ray's prologue (tuned on MI355X, profiles/r01_tuning.md) */
         const char *pro_env = getenv("ORT_ANALYTIC_PROLOGUE");
         /* (trees of every size: the collapse rounds 1 and 2 saw with it on the 1M-triangle scene was the lock pool of
-           the exact fallback, ort_kernels.hip recast_exactly -- with that cured the prologue is worth +23 % there) */
+           the exact fallback, ort_lane.h recast_exactly -- with that cured the prologue is worth +23 % there) */
         const float pro_budget = pro_env ? (float)atof(pro_env) : kPrologueBudget;
         /* cheapest kinds first (a sphere test costs about 1.5 box tests, a cylinder about 5), as many as fit */
         auto cost_of = [](const Prim &p) { return p.kind == PRIM_BOX ? 1.0f : p.kind == PRIM_SPHERE ? 1.5f : 5.0f; };

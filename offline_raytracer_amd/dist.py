@@ -21,7 +21,7 @@ import torch.distributed as dist
 
 from . import api
 
-BLOCK = 8  # must match the kernel's implicit job space (ort_kernels.hip: 8x8 blocks)
+BLOCK = 8  # must match the kernel's implicit job space (ort_lane.h: 8x8 blocks)
 
 
 def block_grid(width, height):

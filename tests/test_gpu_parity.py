@@ -258,7 +258,7 @@ def test_five_waves_build_equals_four_waves_build(api, oracle, gpu_scene, monkey
 
 def test_issue_order_of_chunk_jobs_does_not_matter(api, gpu_scene, monkeypatch):
     """CHUNK renders issue their jobs block-major -- [block][chunk][pixel]: all chunks of an 8x8 block together
-    (ort_kernels.hip, "the order in which a CHUNK render issues its jobs") -- instead of chunk-major as in rounds 1-2
+    (ort_lane.h, "the order in which a CHUNK render issues its jobs") -- instead of chunk-major as in rounds 1-2
     (ORT_LPT=0).  Seeds belong to jobs, so the image is the same bit for bit: whole frames with ragged edge blocks, clipped
     rects, 3-way shards, plain loop and ray exchange (whose waves stop parking near the end of the launch: ORT_ENDGAME_JOBS)"""
     scene = gpu_scene("c3_bunny_room")

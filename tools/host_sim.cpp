@@ -2,7 +2,7 @@
  * tools/host_sim.cpp -- DEVELOPER HARNESS, not part of the product and not a test.
  *
  * The dev container has no GPU.  This tool compiles the kernel's lane function
- * (ort_kernels.hip: pt_lane) as ordinary host C++ (-DORT_HOST_SIM) and runs ONE simulated
+ * (ort_lane.h: pt_lane) as ordinary host C++ (-DORT_HOST_SIM) and runs ONE simulated
  * lane over the whole job space, so kernel logic can be debugged against the oracle
  * before spending GPU-box time.  Nothing in offline_raytracer_amd/, tests/, bench.py or
  * __graft_entry__.py builds, imports or runs it; the product library contains no host
@@ -18,7 +18,7 @@ static uint32_t *g_pixel_rng; static int g_W;
 static int g_dbg_x = -1, g_dbg_y = -1; static FILE *g_ray_log;
 #define ORT_SIM_RAY_HOOK(PX_, PY_, O_, D_, T_, N_, M_) do { if ((PX_) == g_dbg_x && (PY_) == g_dbg_y && g_ray_log) { float r_[11] = {O_.x, O_.y, O_.z, D_.x, D_.y, D_.z, T_, N_.x, N_.y, N_.z, 0}; unsigned m_ = (M_); fwrite(r_, 4, 10, g_ray_log); fwrite(&m_, 4, 1, g_ray_log); } } while (0)
 #define ORT_SIM_PIXEL_HOOK(x, y, rng) do { if (g_pixel_rng) g_pixel_rng[(y) * g_W + (x)] = (rng); } while (0)
-#include "../offline_raytracer_amd/csrc/ort_kernels.hip"
+#include "../offline_raytracer_amd/csrc/ort_lane.h"
 
 #include <chrono>
 

@@ -1,13 +1,17 @@
-"""Developer script (dev container): copy the measurements of tools/r3_final2.sh from gpurun_out/r3final2 into profiles/ under their
-round-3 names, make the PMC stamps, and print the figures DESIGN.md quotes.  usage: python3 tools/r3_collect.py"""
+"""Developer script (dev container): copy the measurements of tools/r3_stamp_call.sh (gpurun_out/r3final2: PMC summaries, scaling
+proxy, phase shares) and tools/r3_benchlines.sh (gpurun_out/r3lines: bench lines, kernel stats) into profiles/ under their round-3
+names, make the PMC stamps, and print the figures DESIGN.md quotes.  usage: python3 tools/r3_collect.py"""
 import json, os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "r3final2")
 P = os.path.join(ROOT, "profiles")
-for a, b in (("bench.json", "r03_bench.json"), ("bench_c2.json", "r03_bench_c2.json"), ("bench_c4.json", "r03_bench_c4.json"),
-             ("bench_c5.json", "r03_bench_c5.json"), ("bench_kernel_stats.csv", "r03_bench_kernel_stats.csv"),
-             ("scaling_proxy.json", "r03_scaling_proxy.json")):
-    shutil.copy(os.path.join(SRC, a), os.path.join(P, b))
+LINES = os.path.join(ROOT, "gpurun_out", "r3lines")
+for d, a, b in ((LINES, "bench.json", "r03_bench.json"), (LINES, "bench_c2.json", "r03_bench_c2.json"), (LINES, "bench_c4.json", "r03_bench_c4.json"),
+                (LINES, "bench_c5.json", "r03_bench_c5.json"), (LINES, "bench_tile32.json", "r03_bench_tile32.json"),
+                (LINES, "rehearsal.json", "r03_bench_rehearsal_2ranks_one_gpu.json"), (LINES, "bench_kernel_stats.csv", "r03_bench_kernel_stats.csv"),
+                (SRC, "scaling_proxy.json", "r03_scaling_proxy.json")):
+    if os.path.exists(os.path.join(d, a)):
+        shutil.copy(os.path.join(d, a), os.path.join(P, b))
 for tag, key in (("c3", "c3_bunny_room 1920x1080 1024spp"), ("c2", "c2_analytic 1920x1080 1024spp"), ("c4", "c4_dwarf_room 3840x2160 512spp"),
                  ("c5", "c5_heightfield_708 3840x2160 256spp")):
     shutil.copy(os.path.join(SRC, "stamps", tag + "_summary.txt"), os.path.join(P, "r03_pmc_summary_%s.txt" % tag))
