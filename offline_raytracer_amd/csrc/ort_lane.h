@@ -218,11 +218,11 @@ struct WfView {
 /* ---- kernel ---------------------------------------------------------------------------- */
 enum : int { PS_NEED_JOB = 0, PS_PIXEL = 1, PS_SAMPLE = 2, PS_HIT = 3, PS_DONE = 4 };
 
-#ifdef ORT_HOST_SIM /* one simulated lane: tools/host_sim.cpp */
+#ifdef ORT_HOST_SIM /* one simulated lane per host thread: tools/host_sim.cpp (job draws and counters are atomic: its threads share them) */
 #define ORT_BALLOT(p) ((p) ? 1ull : 0ull)
 #define ORT_POPC64(m) __builtin_popcountll(m)
-#define ORT_NEXT_JOB(p) ((*(p))++)
-#define ORT_COUNT(p, v) (*(p) += (v))
+#define ORT_NEXT_JOB(p) __atomic_fetch_add((p), 1ull, __ATOMIC_RELAXED)
+#define ORT_COUNT(p, v) ((void)__atomic_fetch_add((p), (v), __ATOMIC_RELAXED))
 #define ORT_TRY_LOCK(p) (*(p) == 0u ? (*(p) = 1u, true) : false)
 #define ORT_PEEK(p) (*(p))
 #define ORT_BACKOFF()

@@ -1,14 +1,17 @@
 /*
- * tools/host_sim.cpp -- DEVELOPER HARNESS, not part of the product and not a test.
+ * tools/host_sim.cpp -- DEVELOPER HARNESS, not part of the product: the kernel's lane code on host threads.
  *
  * The dev container has no GPU.  This tool compiles the kernel's lane function
- * (ort_lane.h: pt_lane) as ordinary host C++ (-DORT_HOST_SIM) and runs ONE simulated
- * lane over the whole job space, so kernel logic can be debugged against the oracle
- * before spending GPU-box time.  Nothing in offline_raytracer_amd/, tests/, bench.py or
- * __graft_entry__.py builds, imports or runs it; the product library contains no host
- * build of the render path.
+ * (ort_lane.h: pt_lane) as ordinary host C++ (-DORT_HOST_SIM) and runs one simulated
+ * lane per host thread (SIM_THREADS, default 1) over the job space, so kernel logic can be debugged
+ * against the oracle before spending GPU-box time.  With policy tile32 and SIM_THREADS = cores it is
+ * the Linux counterpart of the reference's own driver: main()'s 1 024 tiles
+ * (macos_main.mm:602-662) handed out by one job counter to a pool of worker threads
+ * (macos_main.mm:565-598 starts eight pthreads on a work queue), every worker a lane of the
+ * kernel.  The library never loads, links or runs it: the render call has no CPU fallback
+ * (tests/test_host.py holds its image against the oracle; nothing else uses it).
  *
- * build: see tools/Makefile     run: host_sim <scn> <base> W H spp seed policy chunk out.f32
+ * build: see tools/Makefile     run: [SIM_THREADS=n] host_sim <scn> <base> W H spp seed policy chunk out.f32
  */
 #define ORT_HOST_SIM 1
 #include <stdint.h>
@@ -20,7 +23,9 @@ static int g_dbg_x = -1, g_dbg_y = -1; static FILE *g_ray_log;
 #define ORT_SIM_PIXEL_HOOK(x, y, rng) do { if (g_pixel_rng) g_pixel_rng[(y) * g_W + (x)] = (rng); } while (0)
 #include "../offline_raytracer_amd/csrc/ort_lane.h"
 
+#include <algorithm>
 #include <chrono>
+#include <thread>
 
 using namespace ort;
 #ifdef ORT_CHAIN_STATS
@@ -87,7 +92,7 @@ int main(int argc, char **argv) {
     if (policy == "pixel") { rv.mode = JOBS_PIXEL; rv.nchunks = 1; rv.job_count = (unsigned long long)rv.my_blocks * 64; }
     else if (policy == "chunk") {
         rv.mode = JOBS_CHUNK; rv.nchunks = spp / chunk; rv.job_count = (unsigned long long)rv.my_blocks * 64 * rv.nchunks;
-        partial.assign((size_t)rv.nchunks * W * H * 3, 0.0f); rv.partial = partial.data();
+        partial.assign((size_t)rv.nchunks * rv.my_blocks * 64 * 3, 0.0f); rv.partial = partial.data(); /* packed block layout: edge blocks are whole */
     } else {
         uint32_t master = seed;
         auto xs = [&]() { master ^= master << 13; master ^= master >> 17; master ^= master >> 5; return master; };
@@ -117,6 +122,7 @@ int main(int argc, char **argv) {
     cold.bfs_queue_cap = (uint32_t)bfsq.size();
     cold.bfs_queue_count = 1;
     sv.force_fallback_mask = getenv("SIM_FORCE_FALLBACK") ? (uint32_t)strtoul(getenv("SIM_FORCE_FALLBACK"), 0, 0) : 0xffffffffu;
+    const int n_threads = getenv("SIM_THREADS") ? std::max(1, atoi(getenv("SIM_THREADS"))) : 1;
     if (getenv("SIM_WAVEFRONT")) {
         /* the wavefront schedule with a small slot pool: shade all slots, trace all slots, repeat */
         uint32_t S = (uint32_t)atoi(getenv("SIM_WAVEFRONT"));
@@ -136,6 +142,26 @@ int main(int argc, char **argv) {
             for (uint32_t i = 0; i < S; ++i) wf_trace_slot<true>(sv, nullptr, wf, i, 0, wlds.data(), wspill.data(), 0, c);
         }
         flush_counters(hot, c, true);
+    } else
+    if (n_threads > 1) {
+        /* a pool of workers on one job counter: every worker owns what a GPU lane owns (traversal stack, focal-point cache, its
+           queue of the exact fallback), shares what the lanes share (scene, job counter, work counters, framebuffer) */
+        const bool wide = getenv("SIM_WIDE") != nullptr, diffuse_only = getenv("SIM_DIFFUSE") != nullptr;
+        if (wide && t.nodes4.empty()) { fprintf(stderr, "no wide tree\n"); return 1; }
+        std::vector<std::thread> pool;
+        for (int w = 0; w < n_threads; ++w)
+            pool.emplace_back([&, w]() {
+                SceneView svw = sv;
+                SceneCold coldw = cold;
+                std::vector<uint32_t> q(scene->ref.nodes.size() + 8), lock(1, 0u), stack(kLdsStack * kBlock);
+                std::vector<float> focal(3 * kBlock);
+                coldw.bfs_pool = q.data(); coldw.bfs_locks = lock.data(); coldw.bfs_queue_cap = (uint32_t)q.size(); coldw.bfs_queue_count = 1;
+                svw.cold = &coldw;
+                if (wide) { svw.nodes = (const float4 *)t.nodes4.data(); pt_lane<true, false, false, false, true>(svw, hot, nullptr, stack.data(), focal.data(), 0, (uint32_t)w); }
+                else if (diffuse_only) pt_lane<true, true>(svw, hot, nullptr, stack.data(), focal.data(), 0, (uint32_t)w);
+                else pt_lane<true>(svw, hot, nullptr, stack.data(), focal.data(), 0, (uint32_t)w);
+            });
+        for (auto &th : pool) th.join();
     } else
     if (getenv("SIM_WIDE")) { /* the 4-wide form of the tree (DevNode4, visit_node4) */
         if (t.nodes4.empty()) { fprintf(stderr, "no wide tree\n"); return 1; }
