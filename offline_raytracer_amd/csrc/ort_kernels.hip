@@ -34,6 +34,7 @@ struct Knobs {
     int waves5 = -1;           /* ORT_WAVES5=0 / 1: the plain loop's five-waves-per-SIMD build (default: all-lobes flavour, trees that leave the L2) */
     int endgame_jobs = -1;     /* ORT_ENDGAME_JOBS: the ray exchange drains its stashes over the last n/4 jobs per lane (default 16 = four jobs) */
     int blocks_per_cu = -1;    /* ORT_BLOCKS_PER_CU (takes effect at upload) */
+    int job_batch = -1, batch_tail = -1; /* ORT_JOB_BATCH: job indices a wave draws at a time (0: one draw per job); ORT_BATCH_TAIL: ... until this many jobs per lane are left */
 };
 static int env_int(const char *name, int unset = -1) {
     const char *e = getenv(name);
@@ -62,6 +63,8 @@ static Knobs read_knobs() {
     k.waves5 = env_int("ORT_WAVES5");
     k.endgame_jobs = env_int("ORT_ENDGAME_JOBS");
     k.blocks_per_cu = env_int("ORT_BLOCKS_PER_CU");
+    k.job_batch = env_int("ORT_JOB_BATCH");
+    k.batch_tail = env_int("ORT_BATCH_TAIL");
     return k;
 }
 
@@ -508,7 +511,12 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
            228.6 / 117.0 / 63.5 plain).  ORT_EXCHANGE=0 / 1 forces it. */
         /* ... and not for trees that leave the L2: the 1M-triangle scene runs 1 392 Mpaths/s with it and 1 393 without (round 2:
            1 268 / 1 272), and its stashes would move 3 TB/s through the fabric for that */
-        const bool worth_it = diffuse && cache_resident_tree && rv.job_count >= 24ull * (unsigned long long)grid * kBlock;
+        /* ... and only where rays spend their time in the tree: since a wave draws its jobs in batches of like jobs (draw_job) the
+           plain loop keeps its lanes together by itself, and the exchange pays from an SAH cost of the tree (expected node visits of a
+           random ray through the scene box, ort_tree.cpp) of about 0.09 -- 1080p / 512 spp, exchange / plain loop, Mpaths/s: bunny at
+           scale 3 / 5 / 8 / 12 (SAH cost 0.027 / 0.076 / 0.19 / 0.44) 5 428 / 5 844, 5 143 / 5 151, 3 904 / 3 728, 3 173 / 2 946; dwarf at
+           scale 0.008 / 0.012 / 0.02 / 0.03 (0.018 / 0.040 / 0.11 / 0.25) 5 335 / 5 666, 4 921 / 5 143, 4 454 / 4 276, 3 626 / 3 483 */
+        const bool worth_it = diffuse && cache_resident_tree && scene->tree.sah_cost >= 0.09f && rv.job_count >= 24ull * (unsigned long long)grid * kBlock;
         exch = tabs && rv.mode != JOBS_EXPLICIT && (kn.exchange >= 0 ? kn.exchange != 0 : worth_it) && (!counters || (want_util && diffuse));
         if (exch && kn.refill_below < 0) rv.refill_below = 16; /* stragglers park instead of idling: leave the loop a little earlier */
         if (exch) {
@@ -547,6 +555,19 @@ int device_render(Scene *scene, const ort_render_params *p, const ort_tile_job *
     /* CHUNK renders issue their jobs block-major (see "the order in which a CHUNK render issues its jobs"); ORT_LPT=0:
        chunk-major as in rounds 1-2 (A/B runs; same image either way) */
     if (rv.mode == JOBS_CHUNK && rv.nchunks >= 2u && kn.lpt != 0) rv.block_major = 1u;
+    /* a wave draws its job indices in batches (ort_lane.h: draw_job) until ORT_BATCH_TAIL jobs per lane are left in the job
+       space, then one by one: the end of a launch is dealt as finely as before */
+    if (!wavefront) {
+        /* 64 indices at a time, 128 on launches of 96 jobs per lane and more; what a wave holds back is at most two jobs per lane of
+           its own, of up to eight average job lengths each in the expensive blocks: batches stop 8 (16) jobs per lane before the
+           end.  Whole headline frame / its 8-way shard, ms: no batches 422.5 / 63.7, 32: 418.9 / 63.1, 64: 414.3 / 62.0, 128: 411.3 /
+           74.4 (with the tail of 64), 256: 419.9 / 113 (profiles/r03_tuning.md) */
+        const unsigned long long lanes = (unsigned long long)grid * kBlock;
+        rv.job_batch = kn.job_batch >= 0 ? (uint32_t)kn.job_batch : (rv.job_count >= 96ull * lanes ? 128u : 64u);
+        const unsigned long long per_lane = kn.batch_tail >= 0 ? (unsigned long long)kn.batch_tail : 8ull * ((rv.job_batch + 63u) / 64u);
+        const unsigned long long tail = per_lane * lanes;
+        rv.batch_until = rv.job_count > tail ? rv.job_count - tail : 0ull;
+    }
     if (kn.debug_drain && stats && !wavefront) {
         const size_t bytes = (size_t)max_blocks * (kBlock / 64) * sizeof(unsigned long long);
         if ((rc = ensure(&d->drain, &d->drain_bytes, bytes, err))) return rc;

@@ -172,6 +172,8 @@ struct RenderView {
                               (every parked path is a job in progress: the more a wave holds, the longer its tail) */
     uint32_t block_major; /* CHUNK policy: the job space is [block][chunk][pixel] (see below) instead of [chunk][block][pixel] */
     unsigned long long endgame_from; /* ray exchange: job index from which waves stop parking and drain their stashes (pt_lane_x) */
+    uint32_t job_batch;  /* a wave draws this many job indices from next_job at a time and hands them to its lanes one by one (0 / 1: every draw goes to next_job) */
+    unsigned long long batch_until; /* ... while the job counter, as the wave last saw it, is below this index; after it: exactly as many as it needs */
     unsigned long long *drain; /* diagnostics (ORT_DEBUG_DRAIN): when each wave ran out of work (s_memrealtime), [workgroup * 4 + wave] */
 };
 
@@ -889,11 +891,53 @@ ORT_D V3 focal_point(const RenderHot &rv, uint32_t pxy, V3 cam_p, V3 cam_x, V3 c
 /* Advance the lane's path state machine until it has produced the next ray (returns true; the ray
    is P.org / P.dir) or has run out of work (returns false).  On entry with P.ps == PS_HIT, h holds
    the resolved closest hit of the ray produced by the previous call. */
+#ifndef ORT_HOST_SIM
+/* Job indices for the lanes of this wave that need one now (the active lanes).  The wave draws them from next_job in
+   batches -- one returned device-scope atomic, a few microseconds that the whole wave waits for, per job_batch jobs
+   instead of one in every pass in which some lane ends a job -- and keeps the unissued part of its last batch in two
+   words of LDS: pool[0] = next index, pool[1] = end of the batch.  What the batches are really for: consecutive
+   indices are like jobs (block-major order: the 64 pixels of one 8x8 block under one chunk seed), so the lanes of a
+   wave trace like paths and end their jobs together -- plain loop on the headline frame 4 728 -> 5 204 Mpaths/s,
+   analytic scene 3 567 -> 3 886 (profiles/r03_tuning.md).  Near the end of the job space (batch_until) a wave asks
+   for exactly what it needs, so that no wave sits on indices that idle lanes elsewhere could take.  Which lane runs
+   which job cannot change a bit of the image (seeds belong to jobs). */
+ORT_D unsigned long long draw_job(const RenderHot &rv, unsigned long long *pool) {
+    const unsigned long long mask = __ballot(true);
+    const uint32_t n = (uint32_t)__popcll(mask);
+    const uint32_t rank = (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    const unsigned long long next = ((volatile unsigned long long *)pool)[0], end = ((volatile unsigned long long *)pool)[1];
+    const uint32_t avail = (uint32_t)(end - next);
+    unsigned long long j = next + rank;
+    if (n > avail) { /* wave-uniform */
+        const uint32_t need = n - avail;
+        uint32_t want = rv.c->job_batch;
+        if (want < need || end >= rv.c->batch_until) want = need;
+        unsigned long long base = 0ull;
+        if (rank == 0u) base = atomicAdd(rv.c->next_job, (unsigned long long)want);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32));
+        base = ((unsigned long long)hi << 32) | lo;
+        if (rank >= avail) j = base + (rank - avail);
+        if (rank == 0u) { ((volatile unsigned long long *)pool)[0] = base + need; ((volatile unsigned long long *)pool)[1] = base + want; }
+    } else if (rank == 0u) {
+        ((volatile unsigned long long *)pool)[0] = next + n;
+    }
+    return j;
+}
+/* this wave's two words of the workgroup's pool array, emptied; nullptr when draws are not batched */
+ORT_D unsigned long long *wave_job_pool(const RenderHot &rv, unsigned long long *lds_pool) {
+    unsigned long long *pool = lds_pool + 2u * (threadIdx.x >> 6);
+    if ((threadIdx.x & 63u) == 0u) { ((volatile unsigned long long *)pool)[0] = 0ull; ((volatile unsigned long long *)pool)[1] = 0ull; }
+    return rv.c->job_batch > 1u ? pool : nullptr;
+}
+#endif
+
 /* IMPLICIT: the caller vouches for an implicit job space (PIXEL / CHUNK policies: every job is one pixel, spp_u
    samples): the job's rect, its sample count and its index then need no registers of their own */
 template <bool COUNTERS, bool DIFFUSE = false, bool TABS = false, bool IMPLICIT = false>
 ORT_D bool produce_ray(const SceneView &sv, const RenderHot &rv, const float4 *tab, PathState &P, const HitState &h, Counters &c, Prof &pr,
-                       float *focal_cache = nullptr, int focal_stride = 0, uint32_t spp_u = 0, uint32_t *late_flag = nullptr, bool no_new_job = false) {
+                       float *focal_cache = nullptr, int focal_stride = 0, uint32_t spp_u = 0, uint32_t *late_flag = nullptr, bool no_new_job = false,
+                       unsigned long long *pool = nullptr) {
     const V3 cam_p = mk(sv.cam[0], sv.cam[1], sv.cam[2]);
     const V3 cam_x = mk(sv.cam[3], sv.cam[4], sv.cam[5]);
     const V3 cam_y = mk(sv.cam[6], sv.cam[7], sv.cam[8]);
@@ -996,7 +1040,12 @@ ORT_D bool produce_ray(const SceneView &sv, const RenderHot &rv, const float4 *t
             }
             if (P.ps == PS_NEED_JOB) {
                 if (no_new_job) return false; /* ray exchange, end of the launch: this lane takes a parked path first (pt_lane_x) */
-                unsigned long long j = ORT_NEXT_JOB(rv.c->next_job);
+                unsigned long long j;
+#ifndef ORT_HOST_SIM
+                if (pool) j = draw_job(rv, pool);
+                else
+#endif
+                j = ORT_NEXT_JOB(rv.c->next_job);
                 if (j >= rv.c->job_count) { P.ps = PS_DONE; break; }
                 if (IMPLICIT && late_flag && j >= rv.c->endgame_from) *late_flag = 1u; /* ray exchange: the launch is near its end (pt_lane_x) */
                 if (!IMPLICIT && rv.mode == JOBS_EXPLICIT) {
@@ -1410,7 +1459,7 @@ ORT_D void flush_counters(const RenderHot &rv, const Counters &c, bool all) {
 /* persistent mode: one lane runs jobs until the job space is empty */
 template <bool COUNTERS, bool DIFFUSE = false, bool TABS = false, bool IMPLICIT = false, bool WIDE = false>
 ORT_D void pt_lane(const SceneView &sv, const RenderHot &rv, const float4 *tab, uint32_t *lds_stack, float *lds_focal, const int tid,
-                   const uint32_t lane_id, bool prof_on = false) {
+                   const uint32_t lane_id, bool prof_on = false, unsigned long long *pool = nullptr) {
     uint32_t spill[kSpillStack];
     const uint32_t spp_u = IMPLICIT ? ((rv.mode == JOBS_PIXEL) ? rv.c->spp : rv.c->chunk) : 0u; /* samples per (one-pixel) job */
     Prof pr;
@@ -1430,7 +1479,7 @@ ORT_D void pt_lane(const SceneView &sv, const RenderHot &rv, const float4 *tab, 
             ORT_PHASE(pr, sv, 7, true);
             if (P.ps == PS_HIT) resolve_hit<COUNTERS, TABS, kLdsStack, kBlock, true, WIDE>(sv, tab, P.org, P.dir, T.inv_d, lane_id, h, c, pr, lds_stack, spill, tid);
             ORT_PHASE(pr, sv, 0, P.ps == PS_HIT);
-            tracing = produce_ray<COUNTERS, DIFFUSE, TABS, IMPLICIT>(sv, rv, tab, P, h, c, pr, lds_focal + tid, kBlock, spp_u);
+            tracing = produce_ray<COUNTERS, DIFFUSE, TABS, IMPLICIT>(sv, rv, tab, P, h, c, pr, lds_focal + tid, kBlock, spp_u, nullptr, false, pool);
             if (tracing) {
                 begin_ray<COUNTERS, TABS, kLdsStack, kBlock>(sv, tab, P, T, h, c, pr, lds_stack, spill, tid);
                 if (COUNTERS) c.rays++;
@@ -1507,7 +1556,7 @@ ORT_D void stash_load(const Stash &st, uint32_t slot, const RenderHot &rv, PathS
 
 template <bool COUNTERS, bool DIFFUSE, bool TABS>
 ORT_D void pt_lane_x(const SceneView &sv, const RenderHot &rv, const float4 *tab, uint32_t *lds_stack, float *lds_focal, const int tid,
-                     const uint32_t lane_id, bool prof_on) {
+                     const uint32_t lane_id, bool prof_on, unsigned long long *pool) {
     uint32_t spill[kSpillStack];
     Prof pr;
     pr.on = prof_on;
@@ -1637,7 +1686,7 @@ ORT_D void pt_lane_x(const SceneView &sv, const RenderHot &rv, const float4 *tab
             /* near the end of the launch a lane whose job ends draws no new one while the wave still holds parked paths: the
                next exchange step hands it one of those (endgame branch above), so that the stashes are empty when the job
                space is */
-            tracing = produce_ray<COUNTERS, DIFFUSE, TABS, true>(sv, rv, tab, P, h, c, pr, focal_cache, kBlock, spp_u, late_flag, early_end && ltop + rtop > 0u);
+            tracing = produce_ray<COUNTERS, DIFFUSE, TABS, true>(sv, rv, tab, P, h, c, pr, focal_cache, kBlock, spp_u, late_flag, early_end && ltop + rtop > 0u, pool);
             if (tracing) {
                 begin_ray<COUNTERS, TABS, kLdsStack, kBlock>(sv, tab, P, T, h, c, pr, lds_stack, spill, tid);
                 if (COUNTERS) c.rays++;
@@ -1751,6 +1800,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(ORT
 pt_persistent(SceneView sv, RenderHot rv) {
     __shared__ uint32_t lds_stack[kLdsStack * kBlock];
     __shared__ float lds_focal[3 * kBlock]; /* focal[component][lane] */
+    __shared__ unsigned long long lds_pool[2 * (kBlock / 64)]; /* per wave: the unissued part of its last batch of job indices (draw_job) */
     __shared__ float4 lds_tab[TABS ? kTabF4 : 1];
     if (TABS) fill_tab(sv, lds_tab);
     const bool prof = COUNTERS && sv.util != nullptr && blockIdx.x < 32u;
@@ -1759,7 +1809,8 @@ pt_persistent(SceneView sv, RenderHot rv) {
         if (threadIdx.x < 4) g_lds_prof[96 + threadIdx.x] = __builtin_amdgcn_s_memtime();
         __syncthreads();
     }
-    pt_lane<COUNTERS, DIFFUSE, TABS, IMPLICIT, WIDE>(sv, rv, lds_tab, lds_stack, lds_focal, (int)threadIdx.x, blockIdx.x * (uint32_t)kBlock + threadIdx.x, prof);
+    pt_lane<COUNTERS, DIFFUSE, TABS, IMPLICIT, WIDE>(sv, rv, lds_tab, lds_stack, lds_focal, (int)threadIdx.x, blockIdx.x * (uint32_t)kBlock + threadIdx.x, prof,
+                                                    wave_job_pool(rv, lds_pool));
     if ((threadIdx.x & 63u) == 0u && rv.c->drain) rv.c->drain[blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memrealtime();
     if (prof) {
         __syncthreads();
@@ -1773,6 +1824,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(ORT
 pt_persistent_x(SceneView sv, RenderHot rv) {
     __shared__ uint32_t lds_stack[kLdsStack * kBlock];
     __shared__ float lds_focal[4 * kBlock]; /* rows 0-2 focal point, row 3 "this lane drew a job near the end of the launch" (u32) */
+    __shared__ unsigned long long lds_pool[2 * (kBlock / 64)]; /* per wave: the unissued part of its last batch of job indices (draw_job) */
     __shared__ float4 lds_tab[kTabF4];
     fill_tab(sv, lds_tab);
     const bool prof = COUNTERS && sv.util != nullptr && blockIdx.x < 32u;
@@ -1781,7 +1833,8 @@ pt_persistent_x(SceneView sv, RenderHot rv) {
         if (threadIdx.x < 4) g_lds_prof[96 + threadIdx.x] = __builtin_amdgcn_s_memtime();
         __syncthreads();
     }
-    pt_lane_x<COUNTERS, DIFFUSE, true>(sv, rv, lds_tab, lds_stack, lds_focal, (int)threadIdx.x, blockIdx.x * (uint32_t)kBlock + threadIdx.x, prof);
+    pt_lane_x<COUNTERS, DIFFUSE, true>(sv, rv, lds_tab, lds_stack, lds_focal, (int)threadIdx.x, blockIdx.x * (uint32_t)kBlock + threadIdx.x, prof,
+                                       wave_job_pool(rv, lds_pool));
     if ((threadIdx.x & 63u) == 0u && rv.c->drain) rv.c->drain[blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memrealtime();
     if (prof) {
         __syncthreads();
