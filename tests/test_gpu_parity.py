@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import ref_io
-from conftest import GOLDEN, ROOT, assert_bits_equal
+from conftest import DATA, GOLDEN, ROOT, assert_bits_equal
 
 pytestmark = pytest.mark.gpu
 
@@ -280,6 +280,36 @@ def test_issue_order_of_chunk_jobs_does_not_matter(api, gpu_scene, monkeypatch):
         assert_bits_equal(a, acc, "%s, 3-way shard union" % (env,))
         for k in env:
             monkeypatch.delenv(k)
+
+
+def test_job_batches_do_not_change_a_bit(api, gpu_scene, oracle, monkeypatch):
+    """A wave draws its job indices from the job counter in batches and deals them to its lanes (ort_lane.h: draw_job;
+    ORT_JOB_BATCH, ORT_BATCH_TAIL).  Which lane runs which job cannot matter: every batch size -- none, odd, larger than
+    the job space -- with and without the exact draws near the end, in every kernel family (plain loop at four and five
+    waves, ray exchange), PIXEL and CHUNK policies, clipped rects (indices outside the rect are skipped and drawn
+    again inside the same call), explicit job lists: equal to the unbatched render and to the oracle, bit for bit."""
+    for name, w, h, spp, chunk in (("c3_bunny_room", 333, 187, 24, 2), ("c2_analytic", 203, 117, 16, 4)):
+        scene = gpu_scene(name)
+        monkeypatch.setenv("ORT_JOB_BATCH", "0")
+        a, _ = scene.render(w, h, spp, 9, "chunk", chunk=chunk)
+        p0, _ = scene.render(w, h, 4, 9, "pixel")
+        monkeypatch.delenv("ORT_JOB_BATCH")
+        sc = api.Scene.load_scn(os.path.join(DATA, name + ".scn")).commit()
+        ref, _ = oracle.OracleScene(sc.flatten(w, h)).render(w, h, spp, 9, "chunk", chunk=chunk, threads=8)
+        assert_bits_equal(a, ref, "%s unbatched vs the oracle" % name)
+        for env in ({}, {"ORT_JOB_BATCH": "7"}, {"ORT_JOB_BATCH": "64", "ORT_BATCH_TAIL": "0"}, {"ORT_JOB_BATCH": "1000000"},
+                    {"ORT_JOB_BATCH": "33", "ORT_EXCHANGE": "1", "ORT_BATCH_TAIL": "1"}, {"ORT_JOB_BATCH": "128", "ORT_EXCHANGE": "0", "ORT_WAVES5": "1"},
+                    {"ORT_JOB_BATCH": "5", "ORT_EXCHANGE": "0", "ORT_WAVES5": "0", "ORT_BATCH_TAIL": "0"}):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            b, _ = scene.render(w, h, spp, 9, "chunk", chunk=chunk)
+            assert_bits_equal(a, b, "%s %s" % (name, env))
+            r, _ = scene.render(w, h, spp, 9, "chunk", chunk=chunk, rect=(37, 21, 190, 100))
+            assert_bits_equal(a[21:100, 37:190], r[21:100, 37:190], "%s %s, clipped rect" % (name, env))
+            p1, _ = scene.render(w, h, 4, 9, "pixel")
+            assert_bits_equal(p0, p1, "%s %s, PIXEL policy" % (name, env))
+            for k in env:
+                monkeypatch.delenv(k)
 
 
 def test_determinism(api, gpu_scene):
