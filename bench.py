@@ -21,8 +21,8 @@ Prints ONE JSON line on rank 0 with the contract fields plus
                  The memory side stays in `hbm`: SURVEY 8d's algorithmic bytes from exact device
                  counters WITHOUT the analytic prologue's records (wave-uniform reads served from
                  the LDS tables, not memory traffic) against the 8 TB/s peak (`frac`), the PMC-measured
-                 HBM bytes/s (`measured_gbs`; with the ray exchange on about 8 % of the peak, mostly
-                 the parking traffic of the stashes), and 8d's figure as written (`contract_frac`,
+                 HBM bytes/s (`measured_gbs`; where the ray exchange runs about 8 % of the peak, mostly
+                 the parking traffic of the stashes; under the plain loop of the headline 0.5 %), and 8d's figure as written (`contract_frac`,
                  saturated: kept for continuity only).  Without a stamp that matches the kernel
                  sources and the workload the line falls back to bound "hbm" on the divergent bytes
                  and says so.
